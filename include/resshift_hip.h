@@ -1,0 +1,151 @@
+/* resshift_hip.h — C ABI of the MI355X-native ResShift sampling engine (libresshift_hip.so).
+ *
+ * The reference (zsyOAOA/ResShift) is pure Python/PyTorch and has no FFI of its own; its only
+ * extension point is the YAML `target:` string resolved by utils/util_common.py:19-29.  The entry
+ * points below are therefore exactly what a ctypes binding of the reference's hot path needs:
+ * each one replaces the body of one reference call (file:line cited per function), takes plain
+ * pointers and sizes, and never sees a torch type.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (rs_last_error() has the text);
+ *   - "dev" pointers are device pointers valid on the current HIP device (e.g. torch
+ *     Tensor.data_ptr()); the engine never frees caller memory;
+ *   - user-facing image / latent tensors are NCHW fp32 like the reference's; the NHWC fp16/fp32
+ *     working layout is internal;
+ *   - work is enqueued on the caller's hipStream_t (pass torch's current stream); one engine per
+ *     device, not thread-safe;
+ *   - precision: RS_PREC_F16 = fp16 storage / fp32 accumulate MFMA, RS_PREC_F32 = fp32 storage /
+ *     exact fp32 MFMA.
+ */
+#ifndef RESSHIFT_HIP_H
+#define RESSHIFT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_PREC_F16 0
+#define RS_PREC_F32 1
+#define RS_MAX_LEVELS 8
+#define RS_MAX_STEPS 64
+
+typedef struct rs_engine rs_engine;
+
+/* models/unet.py:632-657 (UNetModelSwin.__init__ arguments that shape the network) */
+typedef struct rs_unet_config {
+    int image_size, in_channels, model_channels, out_channels;
+    int n_levels;
+    int channel_mult[RS_MAX_LEVELS];
+    int num_res_blocks[RS_MAX_LEVELS];
+    int n_attn_res;
+    int attention_resolutions[RS_MAX_LEVELS];
+    int swin_depth, swin_embed_dim, window_size, num_heads;
+    float mlp_ratio;
+    int cond_lq, cond_mask, lq_size;
+} rs_unet_config;
+
+/* ldm/models/autoencoder.py:13-26 + ldm/modules/diffusionmodules/model.py:452-456,550-554 (ddconfig) */
+typedef struct rs_ae_config {
+    int ch, n_levels;
+    int ch_mult[RS_MAX_LEVELS];
+    int num_res_blocks[RS_MAX_LEVELS];   /* per level (an int in the YAML is broadcast, model.py:464-468) */
+    int in_channels, out_ch, z_channels, embed_dim, n_embed, resolution;
+    int n_attn_res;
+    int attn_resolutions[RS_MAX_LEVELS];
+} rs_ae_config;
+
+typedef struct rs_config {
+    rs_unet_config unet;
+    rs_ae_config ae;
+    int has_ae;
+    int enable_f16;   /* pack fp16 weights  */
+    int enable_f32;   /* pack fp32 weights (exact mode) */
+} rs_config;
+
+/* Arguments of one full sampling call: gaussian_diffusion.py:367-472 (p_sample_loop) */
+typedef struct rs_sample_args {
+    const float* y;        /* dev, [B,3,h,w] LR image in [-1,1]                     */
+    const float* mask;     /* dev, [B,1,h,w] or NULL (inpainting, sampler.py:140)    */
+    const float* noise;    /* dev, [steps+1][B,Cz,hz,wz]: prior noise then one per step in loop order (t=T-1..0) */
+    float* out;            /* dev, [B,3,h*sf,w*sf] decoded image (not clamped)       */
+    float* z_out;          /* dev, optional [B,Cz,hz,wz] final latent before VQ      */
+    int32_t* idx_out;      /* dev, optional [B*hz*wz] VQ code indices                */
+    int B, h, w, sf, steps;
+    /* per-step scalars, index = timestep t (float64 numpy -> float, gaussian_diffusion.py:143-161,602) */
+    float inv_std[RS_MAX_STEPS];   /* 1/sqrt(eta_t*kappa^2+1)              (_scale_input)       */
+    float coef1[RS_MAX_STEPS];     /* eta_{t-1}/eta_t                      (posterior_mean_coef1) */
+    float coef2[RS_MAX_STEPS];     /* alpha_t/eta_t                        (posterior_mean_coef2) */
+    float sigma[RS_MAX_STEPS];     /* exp(0.5*posterior_log_variance_clipped[t])              */
+    int tmap[RS_MAX_STEPS];        /* respace.py:61-70 timestep_map                           */
+    float prior_scale;             /* kappa*sqrt_eta_{T-1}                 (prior_sample)       */
+    float scale_factor;            /* diffusion.params.scale_factor                           */
+    int prec_encode, prec_decode;
+    int prec_unet[RS_MAX_STEPS];   /* precision of the UNet call at timestep t */
+    void* stream;                  /* hipStream_t */
+} rs_sample_args;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+rs_engine* rs_create(const rs_config* cfg);
+void rs_destroy(rs_engine* e);
+const char* rs_last_error(void);
+
+/* ---- weights: replaces utils/util_net.py:86-98 (reload_model) + sampler.py:108-112 ----------- */
+/* hand over one state_dict entry (fp32 host memory, reference key name, reference shape) */
+int rs_load_tensor(rs_engine* e, const char* state_dict_key, const float* host, const int64_t* shape, int ndim);
+/* size of the packed device blob for this config; layout is a pure function of the config */
+size_t rs_weight_bytes(rs_engine* e);
+/* caller-owned device storage for the blob (so the caller can RCCL-broadcast it as one message) */
+int rs_bind_weight_blob(rs_engine* e, void* dev, size_t bytes);
+/* pack everything loaded so far into the bound blob (GEMM-ready [Cout][kh][kw][Cin] fp16/fp32,
+ * expanded relative-position bias tables, codebook, ...); only the broadcasting rank needs to call it */
+int rs_pack_weights(rs_engine* e);
+/* tell the engine the blob content is valid (after pack or after a broadcast) */
+int rs_weights_ready(rs_engine* e);
+
+/* ---- network calls ------------------------------------------------------------------------- */
+/* models/unet.py:865-895 UNetModelSwin.forward(x, timesteps, lq, mask).  x [B,Cz,H,W], lq [B,3,Hl,Wl],
+ * mask [B,1,Hl,Wl] or NULL, out [B,out_channels,H,W]; t_host = B timestep values on the host. */
+int rs_unet_forward(rs_engine* e, const float* x, const int* t_host, const float* lq, const float* mask, float* out,
+                    int B, int H, int W, int Hl, int Wl, int prec, void* stream);
+/* ldm/models/autoencoder.py:28-31 VQModelTorch.encode: img [B,3,H,W] -> z [B,embed_dim,H/f,W/f] */
+int rs_vq_encode(rs_engine* e, const float* img, float* z, int B, int H, int W, int prec, void* stream);
+/* ldm/models/autoencoder.py:33-40 VQModelTorch.decode: z [B,embed_dim,h,w] -> img [B,out_ch,h*f,w*f] */
+int rs_vq_decode(rs_engine* e, const float* z, float* img, int32_t* idx_out, int B, int h, int w, int force_not_quantize,
+                 int prec, void* stream);
+/* F.interpolate(y, scale_factor=sf, mode='bicubic') — gaussian_diffusion.py:503-504; NCHW in / NCHW out */
+int rs_bicubic(rs_engine* e, const float* y, float* out, int B, int C, int H, int W, int sf, void* stream);
+/* the whole loop: encode_first_stage -> prior_sample -> steps x (UNet + posterior update) -> decode */
+int rs_sample(rs_engine* e, const rs_sample_args* a);
+/* fp32 y = a*x + b*z + c*n on device (posterior mean / prior sample for the step-wise API) */
+int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long count, void* stream);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+/* bytes of scratch arena currently allocated; number of kernel launches issued by the last call */
+size_t rs_arena_bytes(rs_engine* e);
+long long rs_last_launch_count(rs_engine* e);
+
+/* ---- op-level entry points (used by tests/ to check each kernel against torch on its own) ---- */
+/* NHWC conv / linear through the MFMA implicit GEMM or the direct kernels (auto-selected).
+ * x0 [B,Hs,Ws,C0] (+ optional x1 [B,Hs,Ws,C1] concatenated on C), w_ref in the reference layout
+ * [Cout][C0+C1][KH][KW] fp32 on the HOST (packed internally), bias fp32 host or NULL, res/out NHWC. */
+int rs_op_conv2d(const void* x0, const void* x1, const float* w_ref_host, const float* bias_host, const void* res, void* y,
+                 int B, int Hs, int Ws, int C0, int C1, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
+                 int Wo, int up, int act, int in_prec, int out_prec, int force_direct, void* stream);
+/* batched NT GEMM: y[z][m][n] = scale * sum_k a[z][m][k] * b[z][n][k]  (+bias[n]) */
+int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale,
+                  int in_prec, int out_prec, void* stream);
+int rs_op_groupnorm(const void* x, void* y, const float* gamma_host, const float* beta_host, const float* film_dev, int B, int HW,
+                    int C, int groups, float eps, int act, int prec, void* stream);
+int rs_op_window_attention(const void* qkv, void* out, const float* bias_table_host /*[225][heads]*/, int B, int H, int W,
+                           int heads, int shift, int prec, void* stream);
+int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream);
+int rs_op_vq(const float* z, const float* codebook_dev, float* zq, int32_t* idx, long long N, int NE, int D, void* stream);
+int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out_prec, void* stream);
+int rs_op_nhwc_to_nchw(const void* in, float* out, int B, int C, int HW, int in_prec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESSHIFT_HIP_H */

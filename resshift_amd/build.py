@@ -1,0 +1,65 @@
+"""Build libresshift_hip.so (gfx950) in-tree with hipcc.  No GPU is needed: hipcc cross-compiles.
+
+    python -m resshift_amd.build [--force]
+
+The shared library lands next to this file so that it travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libresshift_hip.so")
+SOURCES = ["igemm.hip", "direct_conv.hip", "norm_attn.hip", "elementwise.hip", "engine.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "resshift_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, "stamp.txt")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    if verbose:
+        print(f"[resshift_amd.build] compiling {len(SOURCES)} HIP sources for gfx950 ...", flush=True)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    if verbose:
+        print(f"[resshift_amd.build] built {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

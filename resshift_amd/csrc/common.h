@@ -1,0 +1,96 @@
+// Shared definitions for the ResShift gfx950 kernels.
+//
+// Activation layout everywhere inside the engine: NHWC ("pixel-major"): tensor
+// [B, H, W, C] with C contiguous.  A "pixel stride" (ld) may exceed C so that a
+// kernel can read or write a channel slice of a wider tensor (free concat).
+//
+// Two storage types are supported by every kernel:
+//   RS_F16: _Float16 storage, fp32 accumulation (v_mfma_f32_16x16x32_f16)
+//   RS_F32: float storage, exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum RsDType { RS_F16 = 0, RS_F32 = 1 };
+enum RsAct { RS_ACT_NONE = 0, RS_ACT_GELU = 1, RS_ACT_SILU = 2 };
+
+static inline size_t rs_dtype_size(int dt) { return dt == RS_F16 ? 2 : 4; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float rs_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact-erf GELU (nn.GELU() default; reference models/swin_transformer.py:18)
+__device__ __forceinline__ float rs_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float rs_apply_act(float x, int act) {
+    if (act == RS_ACT_GELU) return rs_gelu(x);
+    if (act == RS_ACT_SILU) return rs_silu(x);
+    return x;
+}
+
+template <typename T> struct Vec8;  // 8 consecutive elements of T
+template <> struct Vec8<f16> {
+    f16x8 v;
+    __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
+    __device__ __forceinline__ void store(f16* p) const { *(f16x8*)p = v; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
+};
+template <> struct Vec8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+    __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
+};
+
+// ---- launch parameter blocks (plain C structs, passed by value) ------------
+
+// Implicit-GEMM convolution / GEMM (igemm.hip).  y[m][n] = sum_k X[m][k] W[n][k]
+// with X gathered on the fly from NHWC sources (im2col never materialised).
+struct IGemmParams {
+    const void* x0;      // source 0, NHWC [B,Hs,Ws,(ld0)]
+    const void* x1;      // optional source 1 (channel-concatenated after x0), may be null
+    const void* w;       // weights [Cout][KH*KW*(C0+C1)], k = (ky*KW+kx)*Ctot + c
+    const float* bias;   // [Cout] fp32 or null
+    const void* res;     // residual (output dtype) [M][ldres] or null
+    void* y;             // output [M][ldy]
+    int C0, C1, ld0, ld1;
+    int B, Hs, Ws, up;   // source spatial dims; `up`=2 folds a nearest x2 upsample into addressing
+    int Ho, Wo, KH, KW, stride, pad_t, pad_l;
+    int Cout, ldy, ldres;
+    int M, Ktot;
+    int act;
+    float out_scale;     // applied to the accumulator before bias
+    long long bs_x0, bs_w, bs_y, bs_res;  // blockIdx.z batch strides in elements (batched GEMM mode)
+};
+
+struct DirectConvParams {
+    const void* x0; const void* x1;
+    const float* w;      // fp32, layout [KH*KW*Ctot][Cout] (cout fastest)
+    const float* bias;
+    void* y;
+    int C0, C1, ld0, ld1;
+    int B, Hs, Ws, up, Ho, Wo, KH, KW, stride, pad_t, pad_l;
+    int Cout, ldy, act;
+};
+
+struct GNParams {
+    const void* x; void* y;
+    const float* gamma; const float* beta;
+    const float* film;   // optional [2*C] (scale then shift) for this (timestep); null if none
+    float* partial;      // [B][S][32][2] partial sums
+    int B, HW, C, ldx, ldy, S, groups;
+    float eps; int act;
+};
+
+struct WinAttnParams {
+    const void* qkv;      // [B,H,W,ldq]: feature f = which*E + head*32 + d (swin_transformer.py:121)
+    void* out;            // [B,H,W,ldo]: feature head*32 + d
+    const float* bias_t;  // [heads][64 (key j)][64 (query i)] relative position bias, transposed
+    int B, H, W, heads, shift, ldq, ldo;
+    float scale;
+};

@@ -1,0 +1,226 @@
+// Sampler-side elementwise kernels, layout conversion, bicubic upsampling and the VQ lookup.
+//
+//   layout:   reference tensors are NCHW fp32 (sampler.py / gaussian_diffusion.py); the engine is NHWC.
+//   sampler:  prior_sample gaussian_diffusion.py:517-529; _scale_input :598-609; posterior mean
+//             :210-221; p_sample noise add :358-364.
+//   bicubic:  F.interpolate(mode='bicubic') gaussian_diffusion.py:503-504 (align_corners=False,
+//             A=-0.75, border-clamped taps, no antialias).
+//   VQ:       VectorQuantizer2.forward ldm/modules/vqvae/quantize.py:271-312 (expanded-form distance,
+//             first-minimum argmin, straight-through expression z + (z_q - z)).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* in, TO* out, int B, int C, int HW, int ldo, int coff, float scale) {
+    const long long n = (long long)B * C * HW;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(g % C);
+        const long long bp = g / C;  // b*HW + pix
+        const long long b = bp / HW;
+        const long long pix = bp - b * HW;
+        out[bp * ldo + coff + c] = (TO)(in[(b * C + c) * HW + pix] * scale);
+    }
+}
+
+template <typename TI>
+__global__ void nhwc_to_nchw_kernel(const TI* in, float* out, int B, int C, int HW, int ldi, int coff) {
+    const long long n = (long long)B * C * HW;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const long long pix = g % HW;
+        const long long bc = g / HW;
+        const long long c = bc % C, b = bc / C;
+        out[g] = (float)in[(b * HW + pix) * ldi + coff + c];
+    }
+}
+
+// y = a*x + b*z + c*n   (all fp32, any layout as long as all operands share it)
+__global__ void axpbypcz_kernel(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long cnt) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < cnt; g += (long long)gridDim.x * blockDim.x) {
+        float v = a * x[g];
+        if (z) v += b * z[g];
+        if (n) v += c * n[g];
+        y[g] = v;
+    }
+}
+
+__global__ void clamp_kernel(float* x, float lo, float hi, long long cnt) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < cnt; g += (long long)gridDim.x * blockDim.x)
+        x[g] = fminf(fmaxf(x[g], lo), hi);
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* x, T* y, long long cnt) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < cnt; g += (long long)gridDim.x * blockDim.x)
+        y[g] = (T)rs_silu((float)x[g]);
+}
+
+// out[r][n] = bias[n] + sum_k act_in(x[r][k]) * w[n][k]   (tiny fp32 linears: time embedding / FiLM tables)
+__global__ void small_linear_kernel(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in,
+                                    int silu_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= R * N) return;
+    const int r = g / N, n = g - r * N;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float xv = x[(long long)r * K + k];
+        if (silu_in) xv = xv / (1.0f + expf(-xv));
+        acc = fmaf(xv, w[(long long)n * K + k], acc);
+    }
+    acc += bias ? bias[n] : 0.f;
+    if (silu_out) acc = acc / (1.0f + expf(-acc));
+    y[g] = acc;
+}
+
+// ---- bicubic ----------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// in: NCHW fp32 [B,C,H,W]; out: NHWC TO [B,H*sf,W*sf,ldo] channels [0,C)
+template <typename TO>
+__global__ void bicubic_up_kernel(const float* in, TO* out, int B, int C, int H, int W, int sf, int ldo) {
+    const int Ho = H * sf, Wo = W * sf;
+    const long long n = (long long)B * Ho * Wo * C;
+    const float A = -0.75f;
+    const float rs = 1.0f / (float)sf;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(g % C);
+        long long t = g / C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const float fy = ((float)oy + 0.5f) * rs - 0.5f;
+        const float fx = ((float)ox + 0.5f) * rs - 0.5f;
+        const float fyf = floorf(fy), fxf = floorf(fx);
+        const int iy = (int)fyf, ix = (int)fxf;
+        const float ty = fy - fyf, tx = fx - fxf;
+        float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+        const float* src = in + ((long long)b * C + c) * H * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(iy - 1 + i, 0), H - 1);
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = min(max(ix - 1 + j, 0), W - 1);
+                r += src[(long long)yy * W + xx] * wx[j];
+            }
+            acc += r * wy[i];
+        }
+        out[(((long long)b * Ho + oy) * Wo + ox) * ldo + c] = (TO)acc;
+    }
+}
+
+// ---- VQ nearest codebook entry ------------------------------------------------
+// z: [N][D] fp32 (NHWC latent, D = embed_dim), codebook E: [NE][D].  One thread per token; the
+// codebook and its squared norms live in LDS.  d_j = (|z|^2 + |e_j|^2) - 2 z.e_j evaluated in fp32
+// in the reference's order; strict '<' keeps the first minimum like torch.argmin.
+template <int D>
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* z, const float* cb, float* zq, int* idx_out, long long N, int NE) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* e = (float*)smem;        // [NE][D]
+    float* ee = e + (long long)NE * D;  // [NE]
+    for (int i = threadIdx.x; i < NE * D; i += blockDim.x) e[i] = cb[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < NE; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = __fadd_rn(s, __fmul_rn(e[j * D + d], e[j * D + d]));
+        ee[j] = s;
+    }
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    float zv[D];
+    float zz = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { zv[d] = z[t * D + d]; zz = __fadd_rn(zz, __fmul_rn(zv[d], zv[d])); }
+    float best = 3.4e38f;
+    int bi = 0;
+    for (int j = 0; j < NE; ++j) {
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) dot = fmaf(zv[d], e[j * D + d], dot);
+        const float dist = __fsub_rn(__fadd_rn(zz, ee[j]), __fmul_rn(2.0f, dot));
+        if (dist < best) { best = dist; bi = j; }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float q = e[bi * D + d];
+        zq[t * D + d] = __fadd_rn(zv[d], __fsub_rn(q, zv[d]));  // z + (z_q - z), quantize.py:298
+    }
+    if (idx_out) idx_out[t] = bi;
+}
+
+inline unsigned nblk(long long n, int bs = 256, long long cap = 65536) { return (unsigned)std::min<long long>((n + bs - 1) / bs, cap); }
+
+}  // namespace
+
+extern "C" {
+
+int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C, int HW, int ldo, int coff, float scale, hipStream_t st) {
+    const long long n = (long long)B * C * HW;
+    if (out_dt == RS_F16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, B, C, HW, ldo, coff, scale);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B, C, HW, ldo, coff, scale);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_nhwc_to_nchw_launch(const void* in, int in_dt, float* out, int B, int C, int HW, int ldi, int coff, hipStream_t st) {
+    const long long n = (long long)B * C * HW;
+    if (in_dt == RS_F16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, (const f16*)in, out, B, C, HW, ldi, coff);
+    else hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, (const float*)in, out, B, C, HW, ldi, coff);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_axpbypcz_launch(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long cnt, hipStream_t st) {
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3(nblk(cnt)), dim3(256), 0, st, x, z, n, y, a, b, c, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st) {
+    hipLaunchKernelGGL(clamp_kernel, dim3(nblk(cnt)), dim3(256), 0, st, x, lo, hi, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_silu_launch(const void* x, void* y, int dt, long long cnt, hipStream_t st) {
+    if (dt == RS_F16) hipLaunchKernelGGL((silu_kernel<f16>), dim3(nblk(cnt)), dim3(256), 0, st, (const f16*)x, (f16*)y, cnt);
+    else hipLaunchKernelGGL((silu_kernel<float>), dim3(nblk(cnt)), dim3(256), 0, st, (const float*)x, (float*)y, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(small_linear_kernel, dim3((R * N + 255) / 256), dim3(256), 0, st, x, w, bias, y, R, K, N, silu_in, silu_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int H, int W, int sf, int ldo, hipStream_t st) {
+    const long long n = (long long)B * H * sf * W * sf * C;
+    if (out_dt == RS_F16) hipLaunchKernelGGL((bicubic_up_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, B, C, H, W, sf, ldo);
+    else hipLaunchKernelGGL((bicubic_up_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B, C, H, W, sf, ldo);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_vq_launch(const float* z, const float* codebook, float* zq, int* idx, long long N, int NE, int D, hipStream_t st) {
+    const size_t lds = (size_t)NE * (D + 1) * sizeof(float);
+    if (lds > 160 * 1024) return -2;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    if (D == 3) {
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((vq_nearest_kernel<3>), dim3(blocks), dim3(256), lds, st, z, codebook, zq, idx, N, NE);
+    } else if (D == 4) {
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((vq_nearest_kernel<4>), dim3(blocks), dim3(256), lds, st, z, codebook, zq, idx, N, NE);
+    } else if (D == 8) {
+        (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((vq_nearest_kernel<8>), dim3(blocks), dim3(256), lds, st, z, codebook, zq, idx, N, NE);
+    } else {
+        return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

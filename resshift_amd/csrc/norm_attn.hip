@@ -1,0 +1,304 @@
+// GroupNorm(32) [+FiLM] [+SiLU], Swin window attention core, and row softmax for gfx950.
+//
+//   GroupNorm: models/basic_ops.py:15-17,89-96 (fp32 statistics, eps 1e-5) and
+//              ldm/modules/diffusionmodules/model.py:46-47 (eps 1e-6); FiLM modulation
+//              models/unet.py:198-202; SiLU models/basic_ops.py:10-12, model.py:41-43.
+//   Window attention: models/swin_transformer.py:114-145 (scale, QK^T, relative position bias,
+//              shift mask, softmax, PV) with roll / window_partition / window_reverse
+//              (swin_transformer.py:35-63,252-275) folded into the load/store addressing.
+//   Row softmax: ldm/modules/diffusionmodules/model.py:193 (AE mid-block attention).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- GroupNorm
+// stats: grid (S, B).  Thread (pp, j) owns 8-channel chunk j and walks pixels pp, pp+PP, ...
+// Deterministic: per-thread partial sums go to LDS, one thread per group reduces them in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
+    __shared__ float red[256][17];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int nchunk = p.C >> 3;
+    const int PP = 256 / nchunk;
+    const int tid = threadIdx.x;
+    const int j = tid % nchunk, pp = tid / nchunk;
+    const int pps = (p.HW + p.S - 1) / p.S;
+    const int p0 = s * pps;
+    const int p1 = min(p.HW, p0 + pps);
+    float sum[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
+    if (pp < PP) {
+        const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + j * 8;
+        for (int pix = p0 + pp; pix < p1; pix += PP) {
+            Vec8<T> v;
+            v.load(x + (long long)pix * p.ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = v.get(e); sum[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid][e] = sum[e]; red[tid][8 + e] = sq[e]; }
+    __syncthreads();
+    if (tid < p.groups) {
+        const int cpg = p.C / p.groups;
+        float a = 0.f, q = 0.f;
+        for (int r = 0; r < PP; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                const int t = r * nchunk + (c >> 3);
+                a += red[t][c & 7];
+                q += red[t][8 + (c & 7)];
+            }
+        float* out = p.partial + (((long long)b * p.S + s) * p.groups + tid) * 2;
+        out[0] = a; out[1] = q;
+    }
+}
+
+// apply: grid (S2, B).  y = act( ((x-mean)*rstd*gamma+beta) * (1+scale) + shift )
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ca = (float*)smem;          // [C]
+    float* cb = ca + p.C;              // [C]
+    float* gm = cb + p.C;              // [groups]
+    float* gr = gm + p.groups;         // [groups]
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int cpg = p.C / p.groups;
+    if (tid < p.groups) {
+        float a = 0.f, q = 0.f;
+        for (int s = 0; s < p.S; ++s) {
+            const float* in = p.partial + (((long long)b * p.S + s) * p.groups + tid) * 2;
+            a += in[0]; q += in[1];
+        }
+        const float n = (float)cpg * (float)p.HW;
+        const float mean = a / n;
+        float var = q / n - mean * mean;
+        var = fmaxf(var, 0.f);
+        gm[tid] = mean;
+        gr[tid] = 1.0f / sqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / cpg;
+        float a = p.gamma[c] * gr[g];
+        float bb = p.beta[c] - gm[g] * a;
+        if (p.film) {
+            const float sc = 1.0f + p.film[c];
+            a *= sc;
+            bb = fmaf(bb, sc, p.film[p.C + c]);
+        }
+        ca[c] = a; cb[c] = bb;
+    }
+    __syncthreads();
+    const int nchunk = p.C >> 3;
+    const int nslab = gridDim.x;
+    const int pps = (p.HW + nslab - 1) / nslab;
+    const int p0 = blockIdx.x * pps;
+    const int p1 = min(p.HW, p0 + pps);
+    const long long nitem = (long long)max(0, p1 - p0) * nchunk;
+    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx;
+    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy;
+    for (long long it = tid; it < nitem; it += 256) {
+        const int pix = p0 + (int)(it / nchunk);
+        const int c0 = (int)(it % nchunk) * 8;
+        Vec8<T> v;
+        v.load(x + (long long)pix * p.ldx + c0);
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, rs_apply_act(fmaf(v.get(e), ca[c0 + e], cb[c0 + e]), p.act));
+        o.store(y + (long long)pix * p.ldy + c0);
+    }
+}
+
+}  // namespace
+
+extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, hipStream_t st) {
+    const GNParams& p = *pp;
+    if ((p.C % 8) || (p.C % p.groups) || p.C / 8 > 256 || p.groups > 256 || (p.ldx % 8) || (p.ldy % 8)) return -2;
+    dim3 g1(p.S, p.B), g2(apply_slabs, p.B);
+    const size_t lds = (2 * p.C + 2 * p.groups) * sizeof(float);
+    if (dt == RS_F16) {
+        hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), lds, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- window attention
+
+namespace {
+
+// grid (windows per image, B); block = 64*heads threads; thread (h, i) owns query token i of head h.
+// K and V of the whole window are staged in LDS as fp32; a wave holds one head, so every LDS read in
+// the score / PV loops is a broadcast.
+template <typename T>
+__global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
+    constexpr int HD = 32, WS = 8, NT = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ks = (float*)smem;                      // [heads][64][32]
+    float* vs = ks + p.heads * NT * HD;            // [heads][64][32]
+    int* rid = (int*)(vs + p.heads * NT * HD);     // [64]
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, i = tid & 63;
+    const int nwx = p.W / WS;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    const int b = blockIdx.y;
+    const int E = p.heads * HD;
+    // token i of this window on the shifted grid, and its source pixel (roll by -shift == read (+shift) % size)
+    const int ys = wy * WS + (i >> 3), xs = wx * WS + (i & 7);
+    int sy = ys + p.shift; if (sy >= p.H) sy -= p.H;
+    int sx = xs + p.shift; if (sx >= p.W) sx -= p.W;
+    const long long pix = ((long long)b * p.H + sy) * p.W + sx;
+    const T* src = (const T*)p.qkv + pix * p.ldq + h * HD;
+    float q[HD];
+#pragma unroll
+    for (int c = 0; c < HD; c += 8) {
+        Vec8<T> vq, vk, vv;
+        vq.load(src + c);
+        vk.load(src + E + c);
+        vv.load(src + 2 * E + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            q[c + e] = vq.get(e) * p.scale;
+            ks[(h * NT + i) * HD + c + e] = vk.get(e);
+            vs[(h * NT + i) * HD + c + e] = vv.get(e);
+        }
+    }
+    if (tid < NT && p.shift > 0) {
+        // region ids of calculate_mask (swin_transformer.py:214-236) on the shifted grid
+        const int hr = ys < p.H - WS ? 0 : (ys < p.H - p.shift ? 1 : 2);
+        const int wr = xs < p.W - WS ? 0 : (xs < p.W - p.shift ? 1 : 2);
+        rid[tid] = hr * 3 + wr;
+    }
+    __syncthreads();
+    float sc[NT];
+    const float* kh = ks + h * NT * HD;
+    const float* bt = p.bias_t + (long long)h * NT * NT + i;
+    const int myrid = p.shift > 0 ? rid[i] : 0;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const f32x4* kr = (const f32x4*)(kh + j * HD);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+            const f32x4 kv = kr[c];
+            a = fmaf(q[4 * c + 0], kv[0], a);
+            a = fmaf(q[4 * c + 1], kv[1], a);
+            a = fmaf(q[4 * c + 2], kv[2], a);
+            a = fmaf(q[4 * c + 3], kv[3], a);
+        }
+        a += bt[j * NT];
+        if (p.shift > 0 && rid[j] != myrid) a += -100.0f;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float denom = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { sc[j] = expf(sc[j] - mx); denom += sc[j]; }
+    const float inv = 1.0f / denom;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    const float* vh = vs + h * NT * HD;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float pj = sc[j] * inv;
+        const f32x4* vr = (const f32x4*)(vh + j * HD);
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+            const f32x4 vv = vr[c];
+            o[4 * c + 0] = fmaf(pj, vv[0], o[4 * c + 0]);
+            o[4 * c + 1] = fmaf(pj, vv[1], o[4 * c + 1]);
+            o[4 * c + 2] = fmaf(pj, vv[2], o[4 * c + 2]);
+            o[4 * c + 3] = fmaf(pj, vv[3], o[4 * c + 3]);
+        }
+    }
+    // window_reverse + reverse roll: the result goes back to the pixel the token was read from
+    T* dst = (T*)p.out + pix * p.ldo + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 8) {
+        Vec8<T> ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov.set(e, o[c + e]);
+        ov.store(dst + c);
+    }
+}
+
+}  // namespace
+
+extern "C" int rs_win_attn_launch(const WinAttnParams* pp, int dt, hipStream_t st) {
+    const WinAttnParams& p = *pp;
+    if ((p.H % 8) || (p.W % 8) || p.heads < 1 || p.heads > 8 || (p.ldq % 8) || (p.ldo % 8)) return -2;
+    if (p.shift != 0 && p.shift != 4) return -2;
+    dim3 grid((p.H / 8) * (p.W / 8), p.B), block(64 * p.heads);
+    const size_t lds = (size_t)2 * p.heads * 64 * 32 * sizeof(float) + 64 * sizeof(int);
+    if (dt == RS_F16) {
+        (void)hipFuncSetAttribute((const void*)win_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((win_attn_kernel<f16>), grid, block, lds, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)win_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((win_attn_kernel<float>), grid, block, lds, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- row softmax (fp32 in)
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = is_max ? fmaxf(r, sh[k]) : r + sh[k];
+    return r;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, TO* out, int ncols, long long lds_, long long ldo) {
+    __shared__ float sh[4];
+    const float* row = s + (long long)blockIdx.x * lds_;
+    TO* orow = out + (long long)blockIdx.x * ldo;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x * 4; c < ncols; c += 1024) {
+        const f32x4 v = *(const f32x4*)(row + c);
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    mx = block_reduce(mx, sh, true);
+    float sum = 0.f;
+    for (int c = threadIdx.x * 4; c < ncols; c += 1024) {
+        const f32x4 v = *(const f32x4*)(row + c);
+        sum += expf(v[0] - mx) + expf(v[1] - mx) + expf(v[2] - mx) + expf(v[3] - mx);
+    }
+    sum = block_reduce(sum, sh, false);
+    const float inv = 1.0f / sum;
+    for (int c = threadIdx.x * 4; c < ncols; c += 1024) {
+        const f32x4 v = *(const f32x4*)(row + c);
+        orow[c + 0] = (TO)(expf(v[0] - mx) * inv);
+        orow[c + 1] = (TO)(expf(v[1] - mx) * inv);
+        orow[c + 2] = (TO)(expf(v[2] - mx) * inv);
+        orow[c + 3] = (TO)(expf(v[3] - mx) * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int rs_softmax_rows_launch(const float* s, void* out, int out_dt, long long nrows, int ncols, long long lds_, long long ldo,
+                                      hipStream_t st) {
+    if (ncols % 4) return -2;
+    if (out_dt == RS_F16)
+        hipLaunchKernelGGL((softmax_rows_kernel<f16>), dim3((unsigned)nrows), dim3(256), 0, st, s, (f16*)out, ncols, lds_, ldo);
+    else
+        hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3((unsigned)nrows), dim3(256), 0, st, s, (float*)out, ncols, lds_, ldo);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

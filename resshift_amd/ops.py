@@ -1,0 +1,147 @@
+"""Thin torch-tensor wrappers over the op-level C-ABI entry points (rs_op_*).
+
+They exist so that tests/ can check every HIP kernel in isolation against a torch fp32 reference.
+Tensors are NHWC (channels last, contiguous) on the GPU; `prec` 0 = fp16 storage, 1 = fp32 storage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+F16, F32 = _lib.RS_PREC_F16, _lib.RS_PREC_F32
+
+
+def _dt(prec: int) -> torch.dtype:
+    return torch.float16 if prec == F16 else torch.float32
+
+
+def _hostf(t: torch.Tensor):
+    t = t.detach().to("cpu", torch.float32).contiguous()
+    return t, t.data_ptr()
+
+
+def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw=None, up=1, act=0, out_prec=None,
+           force_direct=False):
+    """x0: [B,H,W,C0] (+x1 [B,H,W,C1]); w_ref: reference layout [Cout,Cin,KH,KW]; returns [B,Ho,Wo,Cout]."""
+    lib = _lib.load()
+    in_prec = F16 if x0.dtype == torch.float16 else F32
+    out_prec = in_prec if out_prec is None else out_prec
+    B, Hs, Ws, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[-1]
+    Cout, Cin, KH, KW = w_ref.shape
+    assert Cin == C0 + C1
+    pad_t, pad_l = pad
+    if out_hw is None:
+        Ho = (Hs * up + 2 * pad_t - KH) // stride + 1
+        Wo = (Ws * up + 2 * pad_l - KW) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    y = torch.empty(B, Ho, Wo, Cout, device=x0.device, dtype=_dt(out_prec))
+    wh, wp = _hostf(w_ref)
+    bh, bp = _hostf(bias) if bias is not None else (None, None)
+    rc = lib.rs_op_conv2d(x0.data_ptr(), x1.data_ptr() if x1 is not None else None, wp, bp,
+                          res.data_ptr() if res is not None else None, y.data_ptr(), B, Hs, Ws, C0, C1, Cout, KH, KW, stride,
+                          pad_t, pad_l, Ho, Wo, up, act, in_prec, out_prec, int(force_direct), _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_conv2d")
+    return y
+
+
+def gemm_nt(a, b, bias=None, scale=1.0, out_prec=None):
+    """a: [nz,M,K], b: [nz,N,K] -> [nz,M,N] = scale * a @ b^T (+bias[n], fp32 device tensor)."""
+    lib = _lib.load()
+    in_prec = F16 if a.dtype == torch.float16 else F32
+    out_prec = in_prec if out_prec is None else out_prec
+    nz, M, K = a.shape
+    N = b.shape[1]
+    y = torch.empty(nz, M, N, device=a.device, dtype=_dt(out_prec))
+    rc = lib.rs_op_gemm_nt(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), nz, M, N, K,
+                           float(scale), in_prec, out_prec, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_gemm_nt")
+    return y
+
+
+def groupnorm(x, gamma, beta, eps, act=0, film=None, groups=32):
+    """x: [B,H,W,C]; film: optional fp32 device tensor [2C] (scale, shift)."""
+    lib = _lib.load()
+    prec = F16 if x.dtype == torch.float16 else F32
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    gh, gp = _hostf(gamma)
+    bh, bp = _hostf(beta)
+    rc = lib.rs_op_groupnorm(x.data_ptr(), y.data_ptr(), gp, bp, film.data_ptr() if film is not None else None, B, H * W, Cc, groups,
+                             float(eps), act, prec, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_groupnorm")
+    return y
+
+
+def window_attention(qkv, table, heads, shift):
+    """qkv: [B,H,W,3*heads*32]; table: [225,heads] relative_position_bias_table; returns [B,H,W,heads*32]."""
+    lib = _lib.load()
+    prec = F16 if qkv.dtype == torch.float16 else F32
+    B, H, W, _ = qkv.shape
+    out = torch.empty(B, H, W, heads * 32, device=qkv.device, dtype=qkv.dtype)
+    th, tp = _hostf(table)
+    rc = lib.rs_op_window_attention(qkv.data_ptr(), out.data_ptr(), tp, B, H, W, heads, shift, prec, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_window_attention")
+    return out
+
+
+def softmax_rows(s, out_prec=F32):
+    lib = _lib.load()
+    nrows, ncols = s.shape
+    out = torch.empty(nrows, ncols, device=s.device, dtype=_dt(out_prec))
+    _lib.check(lib.rs_op_softmax_rows(s.data_ptr(), out.data_ptr(), nrows, ncols, out_prec, _lib.current_stream_ptr()), "softmax")
+    return out
+
+
+def vq(z, codebook):
+    """z: [N,D] fp32, codebook [NE,D] fp32 (device) -> (zq [N,D], idx [N] int32)."""
+    lib = _lib.load()
+    N, D = z.shape
+    zq = torch.empty_like(z)
+    idx = torch.empty(N, device=z.device, dtype=torch.int32)
+    _lib.check(lib.rs_op_vq(z.data_ptr(), codebook.data_ptr(), zq.data_ptr(), idx.data_ptr(), N, codebook.shape[0], D,
+                            _lib.current_stream_ptr()), "vq")
+    return zq, idx
+
+
+def nchw_to_nhwc(x, prec=F32):
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, device=x.device, dtype=_dt(prec))
+    _lib.check(lib.rs_op_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), B, Cc, H * W, prec, _lib.current_stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    prec = F16 if x.dtype == torch.float16 else F32
+    out = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(lib.rs_op_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), B, Cc, H * W, prec, _lib.current_stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+def bicubic(y, sf):
+    """F.interpolate(y, scale_factor=sf, mode='bicubic') on NCHW fp32 (no engine weights needed)."""
+    lib = _lib.load()
+    B, Cc, H, W = y.shape
+    cfg = _lib.Config()
+    # a minimal valid config just to own a scratch arena
+    cfg.unet.window_size = 8; cfg.unet.num_heads = 1; cfg.unet.swin_embed_dim = 32; cfg.unet.n_levels = 1
+    cfg.unet.image_size = 8; cfg.unet.model_channels = 32; cfg.unet.in_channels = 3; cfg.unet.out_channels = 3
+    cfg.unet.channel_mult[0] = 1; cfg.unet.num_res_blocks[0] = 1; cfg.unet.swin_depth = 2; cfg.unet.mlp_ratio = 4.0
+    cfg.unet.cond_lq = 1; cfg.unet.lq_size = 8
+    cfg.enable_f16 = 1
+    e = lib.rs_create(C.byref(cfg))
+    if not e:
+        raise RuntimeError(_lib.last_error())
+    out = torch.empty(B, Cc, H * sf, W * sf, device=y.device, dtype=torch.float32)
+    rc = lib.rs_bicubic(e, y.data_ptr(), out.data_ptr(), B, Cc, H, W, sf, _lib.current_stream_ptr())
+    torch.cuda.synchronize()
+    lib.rs_destroy(e)
+    _lib.check(rc, "rs_bicubic")
+    return out

@@ -1,0 +1,293 @@
+"""Per-kernel parity: every HIP kernel against a plain torch fp32 (CPU) reference of the same op.
+
+Tolerances: fp16-storage kernels are compared with the fp32 reference evaluated on the SAME
+fp16-rounded inputs/weights, so only accumulation order and the final fp16 rounding differ
+(rel 2e-3 of the tensor's max); fp32-storage kernels use exact fp32 MFMA (rel 2e-5).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2e-3, torch.float32: 2e-5}
+
+
+def _close(got, ref, tol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def _nhwc(x_nchw, dtype, dev):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+
+
+def _ref_in(x_dev):
+    """fp32 NCHW CPU copy of an NHWC device tensor (after any fp16 rounding)."""
+    return x_dev.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad(t,l), up, act, res, asym
+    (2, 16, 16, 160, 160, 3, 1, (1, 1), 1, 0, True, False),
+    (1, 8, 8, 320, 640, 3, 1, (1, 1), 1, 0, False, False),
+    (2, 16, 16, 192, 768, 1, 1, (0, 0), 1, 1, False, False),   # fc1 + GELU
+    (2, 16, 16, 768, 192, 1, 1, (0, 0), 1, 0, True, False),    # fc2 + residual
+    (2, 16, 16, 192, 576, 1, 1, (0, 0), 1, 0, False, False),   # qkv
+    (1, 16, 16, 160, 160, 3, 2, (1, 1), 1, 0, False, False),   # UNet Downsample
+    (1, 16, 16, 128, 128, 3, 2, (0, 0), 1, 0, False, True),    # AE Downsample (pad bottom/right only)
+    (1, 8, 8, 320, 320, 3, 1, (1, 1), 2, 0, False, False),     # Upsample: nearest x2 folded
+    (1, 24, 40, 128, 256, 3, 1, (1, 1), 1, 0, False, False),   # non-square, M tail
+    (3, 8, 8, 64, 48, 3, 1, (1, 1), 1, 0, False, False),       # N tail (Cout not multiple of tile)
+    (1, 8, 8, 480, 160, 1, 1, (0, 0), 1, 0, False, False),     # K tail with fp16 (480 % 64 != 0)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(gpu, dtype, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, k, stride, pad, up, act, use_res, asym = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xd = _nhwc(x, dtype, gpu)
+    wr = w.to(dtype).float()  # weights are rounded to the storage type inside the engine
+    xr = _ref_in(xd)
+    if up == 2:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if asym:
+        xr = F.pad(xr, (0, 1, 0, 1))
+        ref = F.conv2d(xr, wr, b, stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xr, wr, b, stride=stride, padding=pad[0])
+    if act == 1:
+        ref = F.gelu(ref)
+    res_d = None
+    if use_res:
+        r = torch.randn(ref.shape, generator=g)
+        res_d = _nhwc(r, dtype, gpu)
+        ref = ref + _ref_in(res_d)
+    y = ops.conv2d(xd, w, b, res=res_d, stride=stride, pad=pad, out_hw=(ref.shape[2], ref.shape[3]), up=up, act=act)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, TOL[dtype], f"conv {case} {dtype}")
+
+
+def test_conv_identity_asymmetric(gpu):
+    """A = I check with an asymmetric operand: catches a transposed MFMA output mapping."""
+    from resshift_amd import ops
+
+    C = 128
+    x = torch.arange(2 * 8 * 8 * C, dtype=torch.float32).reshape(2, 8, 8, C) % 251 / 64.0
+    w = torch.zeros(C, C, 1, 1)
+    for i in range(C):
+        w[i, (i * 7 + 3) % C, 0, 0] = 1.0  # permutation matrix (asymmetric)
+    for dtype in (torch.float16, torch.float32):
+        xd = x.to(gpu, dtype)
+        y = ops.conv2d(xd, w, None, pad=(0, 0))
+        torch.cuda.synchronize()
+        ref = xd.float().cpu()[..., [(i * 7 + 3) % C for i in range(C)]]
+        assert torch.equal(y.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_conv_concat_two_sources(gpu, dtype):
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 640, 8, 8, generator=g)
+    x1 = torch.randn(2, 320, 8, 8, generator=g)
+    w = torch.randn(320, 960, 3, 3, generator=g) / math.sqrt(960 * 9)
+    b = torch.randn(320, generator=g)
+    d0, d1 = _nhwc(x0, dtype, gpu), _nhwc(x1, dtype, gpu)
+    ref = F.conv2d(torch.cat([_ref_in(d0), _ref_in(d1)], 1), w.to(dtype).float(), b, padding=1)
+    y = ops.conv2d(d0, w, b, x1=d1)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, TOL[dtype], "concat conv")
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [
+    (2, 16, 16, 6, 160, 3, 1, 0),     # UNet input conv
+    (1, 32, 32, 3, 128, 3, 1, 0),     # AE conv_in
+    (2, 16, 16, 160, 3, 3, 1, 0),     # UNet out head (small Cout, vector path)
+    (1, 16, 16, 512, 8, 3, 1, 0),     # faceir conv_out
+    (1, 16, 16, 3, 3, 1, 1, 0),       # quant_conv
+    (1, 16, 16, 3, 16, 3, 1, 2),      # feature extractor conv + SiLU
+    (1, 16, 16, 16, 32, 3, 2, 0),     # feature extractor downsample
+])
+def test_conv_direct(gpu, in_dtype, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, k, stride, act = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xd = _nhwc(x, in_dtype, gpu)
+    ref = F.conv2d(_ref_in(xd), w, b, stride=stride, padding=k // 2)
+    if act == 2:
+        ref = F.silu(ref)
+    y = ops.conv2d(xd, w, b, stride=stride, pad=(k // 2, k // 2), act=act, out_prec=1, force_direct=True)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, 2e-5, f"direct conv {case}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 160), (1, 8, 8, 1280), (2, 32, 32, 192), (1, 64, 64, 128), (3, 8, 8, 960), (1, 16, 16, 64)])
+@pytest.mark.parametrize("mode", ["plain", "silu", "film_silu"])
+def test_groupnorm(gpu, dtype, shape, mode):
+    from resshift_amd import ops
+
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3
+    gamma = torch.randn(C, generator=g)
+    beta = torch.randn(C, generator=g)
+    xd = _nhwc(x, dtype, gpu)
+    eps = 1e-5 if mode != "plain" else 1e-6
+    ref = F.group_norm(_ref_in(xd), 32, gamma, beta, eps)
+    film_d = None
+    if mode == "film_silu":
+        film = torch.randn(2 * C, generator=g) * 0.5
+        film_d = film.to(gpu)
+        ref = ref * (1 + film[:C].view(1, C, 1, 1)) + film[C:].view(1, C, 1, 1)
+    if mode != "plain":
+        ref = F.silu(ref)
+    y = ops.groupnorm(xd, gamma, beta, eps, act=0 if mode == "plain" else 2, film=film_d)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, 2e-3 if dtype == torch.float16 else 5e-5, f"groupnorm {shape} {mode}")
+
+
+def _window_attention_reference(qkv_nchw, table, heads, shift, ws=8):
+    """Plain restatement of W-MSA/SW-MSA on [B,3E,H,W] -> [B,E,H,W] (roll, partition, bias, mask, softmax, reverse)."""
+    B, C3, H, W = qkv_nchw.shape
+    E = C3 // 3
+    hd = E // heads
+    x = qkv_nchw
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(2, 3))
+    xw = x.view(B, C3, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws, C3)
+    qkv = xw.reshape(-1, ws * ws, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (ws - 1)
+    idx = rel[..., 0] * (2 * ws - 1) + rel[..., 1]
+    attn = attn + table[idx.view(-1)].view(ws * ws, ws * ws, heads).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        img = torch.zeros(1, 1, H, W)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, :, hs, wsl] = cnt
+                cnt += 1
+        mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws)
+        mask = (mw.unsqueeze(1) - mw.unsqueeze(2) != 0).float() * -100.0
+        nW = mask.shape[0]
+        attn = (attn.view(-1, nW, heads, ws * ws, ws * ws) + mask[None, :, None]).view(-1, heads, ws * ws, ws * ws)
+    attn = attn.softmax(-1)
+    o = (attn @ v).transpose(1, 2).reshape(-1, ws, ws, E)
+    o = o.view(B, H // ws, W // ws, ws, ws, E).permute(0, 5, 1, 3, 2, 4).reshape(B, E, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(2, 3))
+    return o
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("hw", [(8, 8), (16, 16), (32, 16)])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_window_attention(gpu, dtype, hw, shift):
+    from resshift_amd import ops
+
+    H, W = hw
+    if shift and min(H, W) <= 8:
+        pytest.skip("shift is disabled when the map is a single window")
+    heads = 6
+    g = torch.Generator().manual_seed(H * 7 + shift)
+    qkv = torch.randn(2, 3 * heads * 32, H, W, generator=g)
+    table = torch.randn(225, heads, generator=g) * 0.5
+    qd = _nhwc(qkv, dtype, gpu)
+    ref = _window_attention_reference(_ref_in(qd), table, heads, shift)
+    out = ops.window_attention(qd, table, heads, shift)
+    torch.cuda.synchronize()
+    _close(out.permute(0, 3, 1, 2), ref, 2e-3 if dtype == torch.float16 else 2e-5, f"window attention {hw} shift {shift}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_gemm_nt_batched_and_softmax(gpu, dtype):
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    nz, T, Cc = 2, 256, 512
+    q = torch.randn(nz, T, Cc, generator=g).to(gpu, dtype)
+    k = torch.randn(nz, T, Cc, generator=g).to(gpu, dtype)
+    s = ops.gemm_nt(q, k, scale=Cc ** -0.5, out_prec=1)
+    torch.cuda.synchronize()
+    ref = (q.float().cpu() @ k.float().cpu().transpose(1, 2)) * Cc ** -0.5
+    _close(s, ref, 2e-5 if dtype == torch.float32 else 1e-4, "QK^T")
+    p = ops.softmax_rows(s.view(nz * T, T), out_prec=1)
+    torch.cuda.synchronize()
+    _close(p, s.float().cpu().view(nz * T, T).softmax(-1), 1e-5, "softmax")
+    # PV with bias: o = P @ V + b  via V^T operand
+    v = torch.randn(nz, T, Cc, generator=g).to(gpu, dtype)
+    vt = v.transpose(1, 2).contiguous()
+    bias = torch.randn(Cc, generator=g).to(gpu)
+    pd = p.view(nz, T, T).to(dtype)
+    o = ops.gemm_nt(pd, vt, bias=bias)
+    torch.cuda.synchronize()
+    ref_o = pd.float().cpu() @ v.float().cpu() + bias.cpu()
+    _close(o, ref_o, TOL[dtype], "PV")
+
+
+@pytest.mark.parametrize("ne_d", [(8192, 3), (4096, 8)])
+def test_vq_nearest(gpu, ne_d):
+    from resshift_amd import ops
+
+    NE, D = ne_d
+    g = torch.Generator().manual_seed(NE)
+    cb = torch.randn(NE, D, generator=g) * 0.6
+    z = torch.randn(4096, D, generator=g)
+    zq, idx = ops.vq(z.to(gpu), cb.to(gpu))
+    torch.cuda.synchronize()
+    d = (z ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * z @ cb.t()
+    ref_idx = d.argmin(1)
+    agree = (idx.cpu().long() == ref_idx).float().mean().item()
+    assert agree >= 0.999, f"VQ index agreement {agree}"
+    # where indices agree the straight-through value must be bit-identical to z + (e - z)
+    m = idx.cpu().long() == ref_idx
+    ref_q = z + (cb[ref_idx] - z)
+    assert torch.equal(zq.cpu()[m], ref_q[m])
+    # and the chosen code must be (numerically) a nearest one everywhere
+    chosen = d.gather(1, idx.cpu().long()[:, None])[:, 0]
+    assert (chosen - d.min(1).values).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("sf", [2, 4])
+def test_bicubic(gpu, sf):
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(sf)
+    y = torch.rand(2, 3, 16, 24, generator=g) * 2 - 1
+    out = ops.bicubic(y.to(gpu), sf)
+    ref = F.interpolate(y, scale_factor=sf, mode="bicubic")
+    _close(out, ref, 2e-6, "bicubic")
+
+
+def test_layout_roundtrip(gpu):
+    from resshift_amd import ops
+
+    x = torch.randn(2, 5, 8, 12)
+    xd = x.to(gpu)
+    nhwc = ops.nchw_to_nhwc(xd, prec=1)
+    assert torch.equal(nhwc.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    back = ops.nhwc_to_nchw(nhwc)
+    assert torch.equal(back.cpu(), x)
