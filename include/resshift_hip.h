@@ -59,7 +59,8 @@ typedef struct rs_ae_config {
 typedef struct rs_config {
     rs_unet_config unet;
     rs_ae_config ae;
-    int has_ae;
+    int has_unet;     /* build the UNetModelSwin graph   */
+    int has_ae;       /* build the VQModelTorch graph    */
     int enable_f16;   /* pack fp16 weights  */
     int enable_f32;   /* pack fp32 weights (exact mode) */
 } rs_config;

@@ -48,7 +48,8 @@ class AEConfig(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("unet", UNetConfig), ("ae", AEConfig), ("has_ae", C.c_int), ("enable_f16", C.c_int), ("enable_f32", C.c_int)]
+    _fields_ = [("unet", UNetConfig), ("ae", AEConfig), ("has_unet", C.c_int), ("has_ae", C.c_int), ("enable_f16", C.c_int),
+                ("enable_f32", C.c_int)]
 
 
 class SampleArgs(C.Structure):

@@ -412,7 +412,7 @@ struct rs_engine {
         blob.base = base; blob.off = 0; blob.fill = fill;
         build_err.clear();
         if (fill) blob.staging.assign(blob_bytes, 0);
-        build_unet();
+        if (cfg.has_unet) build_unet();
         if (cfg.has_ae) build_ae();
         return (blob.off + 255) & ~(size_t)255;
     }
@@ -599,6 +599,7 @@ struct rs_engine {
     }
     void collect_film_blocks() {
         film_blocks.clear();
+        if (!cfg.has_unet) return;
         for (auto& b : in_blocks) if (b.has_res) film_blocks.push_back(&b.res);
         film_blocks.push_back(&mid_res1); film_blocks.push_back(&mid_res2);
         for (auto& b : out_blocks) if (b.has_res) film_blocks.push_back(&b.res);
@@ -837,10 +838,13 @@ const char* rs_last_error(void) { return g_err.c_str(); }
 rs_engine* rs_create(const rs_config* cfg) {
     if (!cfg) { g_err = "null config"; return nullptr; }
     const rs_unet_config& u = cfg->unet;
-    if (u.window_size != 8) { g_err = "only window_size 8 is supported"; return nullptr; }
-    if (u.num_heads < 1 || u.swin_embed_dim != u.num_heads * 32) { g_err = "swin head dim must be 32"; return nullptr; }
-    if (u.n_levels < 1 || u.n_levels > RS_MAX_LEVELS) { g_err = "bad n_levels"; return nullptr; }
-    if ((u.image_size >> (u.n_levels - 1)) < 8) { g_err = "coarsest UNet level must be >= 8x8"; return nullptr; }
+    if (!cfg->has_unet && !cfg->has_ae) { g_err = "config has neither a UNet nor an autoencoder"; return nullptr; }
+    if (cfg->has_unet) {
+        if (u.window_size != 8) { g_err = "only window_size 8 is supported"; return nullptr; }
+        if (u.num_heads < 1 || u.swin_embed_dim != u.num_heads * 32) { g_err = "swin head dim must be 32"; return nullptr; }
+        if (u.n_levels < 1 || u.n_levels > RS_MAX_LEVELS) { g_err = "bad n_levels"; return nullptr; }
+        if ((u.image_size >> (u.n_levels - 1)) < 8) { g_err = "coarsest UNet level must be >= 8x8"; return nullptr; }
+    }
     if (cfg->has_ae && cfg->ae.n_attn_res != 0) { g_err = "AE attn_resolutions must be empty"; return nullptr; }
     if (!cfg->enable_f16 && !cfg->enable_f32) { g_err = "enable at least one precision"; return nullptr; }
     rs_engine* e = new rs_engine();
@@ -909,7 +913,7 @@ long long rs_last_launch_count(rs_engine* e) { return e ? e->last_launches : 0; 
 
 int rs_unet_forward(rs_engine* e, const float* x, const int* t_host, const float* lq, const float* mask, float* out, int B, int H, int W,
                     int Hl, int Wl, int prec, void* stream) {
-    if (!e) return fail("null engine");
+    if (!e || !e->cfg.has_unet) return fail("engine has no UNet");
     {
         const int sh = e->cfg.unet.n_levels - 1;
         if ((H % (8 << sh)) || (W % (8 << sh))) return fail("UNet input H/W must be multiples of 8*2^(levels-1)");
@@ -965,7 +969,7 @@ int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float 
 // gaussian_diffusion.py:367-472: encode_first_stage(up_sample) -> prior_sample -> T x p_sample -> decode_first_stage
 int rs_sample(rs_engine* e, const rs_sample_args* a) {
     if (!e || !a) return fail("null argument");
-    if (!e->cfg.has_ae) return fail("rs_sample needs the autoencoder");
+    if (!e->cfg.has_ae || !e->cfg.has_unet) return fail("rs_sample needs both the UNet and the autoencoder");
     if (a->steps < 1 || a->steps > RS_MAX_STEPS) return fail("bad step count");
     hipStream_t st = (hipStream_t)a->stream;
     if (!e->ready) return fail("weights are not ready");

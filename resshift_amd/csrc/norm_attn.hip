@@ -168,10 +168,10 @@ __global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
         }
     }
     if (tid < NT && p.shift > 0) {
-        // region ids of calculate_mask (swin_transformer.py:214-236) on the shifted grid
-        const int hr = ys < p.H - WS ? 0 : (ys < p.H - p.shift ? 1 : 2);
-        const int wr = xs < p.W - WS ? 0 : (xs < p.W - p.shift ? 1 : 2);
-        rid[tid] = hr * 3 + wr;
+        // region ids of calculate_mask (swin_transformer.py:214-236) on the shifted grid.  The reference indexes its
+        // (1,1,H,W) mask image as [:, h, w, :], so its "h" slices hit the singleton dim and its "w" slices hit the ROW
+        // axis: the effective region id is the row band only (pinned against the reference, oracle/make_golden.py).
+        rid[tid] = ys < p.H - WS ? 0 : (ys < p.H - p.shift ? 1 : 2);
     }
     __syncthreads();
     float sc[NT];

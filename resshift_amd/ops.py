@@ -135,6 +135,7 @@ def bicubic(y, sf):
     cfg.unet.image_size = 8; cfg.unet.model_channels = 32; cfg.unet.in_channels = 3; cfg.unet.out_channels = 3
     cfg.unet.channel_mult[0] = 1; cfg.unet.num_res_blocks[0] = 1; cfg.unet.swin_depth = 2; cfg.unet.mlp_ratio = 4.0
     cfg.unet.cond_lq = 1; cfg.unet.lq_size = 8
+    cfg.has_unet = 1
     cfg.enable_f16 = 1
     e = lib.rs_create(C.byref(cfg))
     if not e:

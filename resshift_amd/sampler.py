@@ -1,0 +1,204 @@
+"""Drop-in `ResShiftSampler` (reference: sampler.py:26-308) on top of the HIP engine.
+
+Same constructor and `sample_func` / `inference` signatures as the reference.  Differences that do not
+change results: models come from the engine-backed classes (the YAML `target:` strings of the
+reference are mapped onto them), every rank can receive the packed weights through ONE RCCL
+broadcast instead of re-reading the checkpoint (sharding.py), and image file I/O uses PIL (the
+reference uses cv2, which is a host-side detail outside the hot path).
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from contextlib import nullcontext
+from pathlib import Path
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import sharding
+from .autoencoder import VQModelTorch
+from .config import ConfigNode, load_config
+from .gaussian_diffusion import create_gaussian_diffusion
+from .unet import UNetModelSwin
+
+# the reference's only plug-in mechanism is the `target:` string (utils/util_common.py:19-29)
+TARGETS = {
+    "models.unet.UNetModelSwin": UNetModelSwin,
+    "models.script_util.create_gaussian_diffusion": create_gaussian_diffusion,
+    "ldm.models.autoencoder.VQModelTorch": VQModelTorch,
+    "resshift_amd.unet.UNetModelSwin": UNetModelSwin,
+    "resshift_amd.gaussian_diffusion.create_gaussian_diffusion": create_gaussian_diffusion,
+    "resshift_amd.autoencoder.VQModelTorch": VQModelTorch,
+}
+
+
+def instantiate_from_config(config: Mapping):
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    try:
+        cls = TARGETS[config["target"]]
+    except KeyError as e:
+        raise NotImplementedError(f"target {config['target']} is outside the accelerated hot path") from e
+    return cls(**dict(config.get("params", {})))
+
+
+def reload_model(model: torch.nn.Module, ckpt: Mapping[str, torch.Tensor]) -> None:
+    """utils/util_net.py:86-98 semantics: tolerate `module.` / `_orig_mod.` prefixes, require every key."""
+    first = next(iter(ckpt.keys()))
+    module_flag = first.startswith("module.")
+    compile_flag = "_orig_mod" in first
+    for key, value in model.state_dict().items():
+        tkey = key
+        if compile_flag:
+            tkey = "_orig_mod." + tkey
+        if module_flag:
+            tkey = "module." + tkey
+        assert tkey in ckpt, f"checkpoint is missing {tkey}"
+        value.copy_(ckpt[tkey])
+
+
+class BaseSampler:
+    def __init__(self, configs, sf=4, use_amp=True, chop_size=128, chop_stride=128, chop_bs=1, padding_offset=16, seed=10000,
+                 state_dicts: Optional[Mapping[str, Mapping[str, torch.Tensor]]] = None):
+        """`state_dicts` ({"model": sd, "autoencoder": sd}) replaces checkpoint files, e.g. for synthetic-weight runs."""
+        self.configs = configs if isinstance(configs, Mapping) else load_config(configs)
+        self.sf = sf
+        self.chop_size, self.chop_stride, self.chop_bs = chop_size, chop_stride, chop_bs
+        self.seed = seed
+        self.use_amp = use_amp
+        self.padding_offset = padding_offset
+        self._state_dicts = state_dicts
+        self.setup_dist()
+        self.setup_seed()
+        self.build_model()
+
+    def setup_seed(self, seed=None):
+        seed = self.seed if seed is None else seed
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+
+    def setup_dist(self, gpu_id=None):
+        """One process per GPU (torchrun); RCCL through torch.distributed backend 'nccl' (sampler.py:66-77)."""
+        self.num_gpus, self.rank = sharding.init_distributed()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def write_log(self, log_str):
+        if self.rank == 0:
+            print(log_str, flush=True)
+
+    def _load_sd(self, which: str, ckpt_path):
+        if self._state_dicts is not None and which in self._state_dicts:
+            return self._state_dicts[which]
+        assert ckpt_path is not None, f"configs.{which}.ckpt_path is required"
+        state = torch.load(ckpt_path, map_location="cpu")
+        return state["state_dict"] if "state_dict" in state else state
+
+    def build_model(self):
+        c = self.configs
+        self.write_log(f"Building the diffusion model with length: {c['diffusion']['params']['steps']}...")
+        self.base_diffusion = instantiate_from_config(c["diffusion"])
+        model = instantiate_from_config(c["model"]).to(self.device)
+        autoencoder = instantiate_from_config(c["autoencoder"]).to(self.device) if c.get("autoencoder") is not None else None
+        if autoencoder is None:
+            raise NotImplementedError("the accelerated path samples in the VQ latent space (all shipped configs)")
+        # rank 0 reads + packs the weights once; the packed blob reaches the other ranks by one RCCL broadcast
+        eng = sharding.build_engine_with_broadcast(
+            model, autoencoder,
+            load_fn=lambda: (self._load_sd("model", c["model"].get("ckpt_path")), self._load_sd("autoencoder", c["autoencoder"].get("ckpt_path"))),
+            rank=self.rank, world=self.num_gpus)
+        self.base_diffusion.adopt_engine(model, autoencoder, eng)
+        self.model = model.eval()
+        self.autoencoder = autoencoder.eval()
+        self.engine = eng
+        # use_amp=True is the reference's fp16 autocast path (sampler.py:185); False runs the exact fp32 kernels
+        self.base_diffusion.set_precision(*( ["fp16"] * 3 if self.use_amp else ["fp32"] * 3 ))
+
+    def set_precision(self, unet=None, encode=None, decode=None):
+        self.base_diffusion.set_precision(unet, encode, decode)
+
+
+class ResShiftSampler(BaseSampler):
+    def sample_func(self, y0, noise_repeat=False, mask=False, noise=None, step_noises=None):
+        """y0: [n,c,h,w] in [-1,1]; returns [n,c,h*sf,w*sf] in [-1,1] (sampler.py:119-165)."""
+        if noise_repeat:
+            self.setup_seed()
+        if mask is False:
+            mask = None
+        offset = self.padding_offset
+        ori_h, ori_w = y0.shape[2:]
+        flag_pad = not (ori_h % offset == 0 and ori_w % offset == 0)
+        if flag_pad:
+            pad_h = (math.ceil(ori_h / offset)) * offset - ori_h
+            pad_w = (math.ceil(ori_w / offset)) * offset - ori_w
+            y0 = sharding.reflect_pad(y0, pad_h, pad_w)
+            if mask is not None:
+                mask = sharding.reflect_pad(mask, pad_h, pad_w)
+        cond_lq = self.configs["model"]["params"].get("cond_lq", True)
+        if cond_lq and mask is not None:
+            model_kwargs = {"lq": y0, "mask": mask}
+        elif cond_lq:
+            model_kwargs = {"lq": y0}
+        else:
+            model_kwargs = None
+        results = self.base_diffusion.p_sample_loop(y=y0, model=self.model, first_stage_model=self.autoencoder, noise=noise,
+                                                    noise_repeat=noise_repeat, clip_denoised=(self.autoencoder is None),
+                                                    denoised_fn=None, model_kwargs=model_kwargs, progress=False,
+                                                    step_noises=step_noises)
+        if flag_pad:
+            results = results[:, :, : ori_h * self.sf, : ori_w * self.sf]
+        return results.clamp_(-1.0, 1.0)
+
+    # ------------------------------------------------------------------ file-level demo driver
+    @staticmethod
+    def _read_image(path) -> torch.Tensor:
+        from PIL import Image
+
+        im = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+        return torch.from_numpy(im).permute(2, 0, 1).contiguous()
+
+    @staticmethod
+    def _write_image(t: torch.Tensor, path) -> None:
+        from PIL import Image
+
+        arr = (t.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0).round().astype(np.uint8)
+        Image.fromarray(arr).save(path)
+
+    def inference(self, in_path, out_path, mask_path=None, mask_back=True, bs=1, noise_repeat=False):
+        """sampler.py:167-308 for inputs that fit one pass (H, W <= chop_size): batches of `bs` images are
+        sharded over the ranks exactly like sampler.py:273-277; every rank writes its own PNGs."""
+        in_path, out_path = Path(in_path), Path(out_path)
+        if self.rank == 0:
+            out_path.mkdir(parents=True, exist_ok=True)
+        sharding.barrier()
+        files = sorted([p for p in (in_path.glob("*") if in_path.is_dir() else [in_path])
+                        if p.suffix.lower() in (".png", ".jpg", ".jpeg", ".bmp")])
+        ctx = torch.autocast("cuda") if (self.use_amp and torch.cuda.is_available()) else nullcontext()
+        for b0 in range(0, len(files), bs):
+            batch = files[b0:b0 + bs]
+            lo, hi = sharding.shard_bounds(len(batch), self.rank, self.num_gpus)
+            mine = batch[lo:hi]
+            if mine:
+                lq = torch.stack([(self._read_image(p) - 0.5) / 0.5 for p in mine]).to(self.device)
+                mask = None
+                if mask_path is not None:
+                    mask = torch.stack([self._read_image(Path(mask_path) / p.name)[:1] for p in mine]).to(self.device)
+                    mask = (mask - 0.5) / 0.5
+                if lq.shape[2] > self.chop_size or lq.shape[3] > self.chop_size:
+                    raise NotImplementedError("tiled inference of large images is scheduled for a later round (SURVEY §8f-1)")
+                with ctx:
+                    sr = self.sample_func(lq, noise_repeat=noise_repeat, mask=mask)
+                sr = sr * 0.5 + 0.5
+                if mask is not None and mask_back:
+                    m01 = mask * 0.5 + 0.5
+                    sr = sr * m01 + (lq * 0.5 + 0.5) * (1 - m01)
+                for p, im in zip(mine, sr):
+                    self._write_image(im, out_path / f"{p.stem}.png")
+        sharding.barrier()
+        self.write_log(f"Processing done, enjoy the results in {out_path}")

@@ -1,0 +1,101 @@
+"""Data-parallel plumbing: one process per GPU, images are independent units.
+
+The reference shards every loader batch by rank (sampler.py:273-277: `micro = ceil(bs / num_gpus)`,
+slice `[rank*micro, (rank+1)*micro)`) and issues no data collective — only barriers (sampler.py:234,291);
+every rank re-reads the checkpoint itself (sampler.py:108-112).  Here rank 0 reads and packs the weights
+once and the packed blob travels to the other GPUs in ONE RCCL broadcast over xGMI
+(`torch.distributed` backend "nccl" is RCCL on ROCm).  Steady state has zero collectives.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Callable, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def init_distributed() -> Tuple[int, int]:
+    """Returns (world_size, rank).  Initialises the process group from the torchrun environment when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", init_method="env://", rank=rank,
+                                world_size=world)
+    return world, rank
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous per-rank slice of a batch of n units (sampler.py:273-277); trailing ranks may be empty."""
+    micro = math.ceil(n / max(1, world))
+    lo = min(n, rank * micro)
+    return lo, min(n, lo + micro)
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int, dim: int = 0) -> torch.Tensor:
+    lo, hi = shard_bounds(t.shape[dim], rank, world)
+    return t.narrow(dim, lo, hi - lo)
+
+
+def shard_noise(noise: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """noise: [steps+1, B_global, C, h, w] drawn for the FULL batch; a sample's noise depends on its position in
+    the global batch, so every rank slices the same global tensor (parity with a single-GPU run)."""
+    return shard_batch(noise, rank, world, dim=1).contiguous()
+
+
+def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """One collective for the whole packed weight blob (flat uint8 tensor)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(blob, src=src)
+    return blob
+
+
+def gather_images(local: torch.Tensor, n_global: int, rank: int, world: int) -> torch.Tensor:
+    """Collect per-rank outputs on every rank in global batch order (host-side convenience, not on the hot path)."""
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return local
+    micro = math.ceil(n_global / world)
+    pad = torch.zeros((micro,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat(parts, 0)[:n_global]
+
+
+def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
+    """F.pad(..., mode='reflect') on the bottom/right (sampler.py:130-138)."""
+    return F.pad(x, pad=(0, pad_w, 0, pad_h), mode="reflect")
+
+
+def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int):
+    """Create the fused UNet+AE engine on this rank's GPU.  Rank 0 calls `load_fn()` -> (unet_sd, ae_sd), fills the
+    drop-in modules (reload_model semantics) and packs the device blob; the blob is then broadcast."""
+    from .engine import Engine
+    from .sampler import reload_model
+
+    dev = next(model.parameters()).device
+    eng = Engine(unet_params=model.params, ae_params=autoencoder.params, device=dev)
+    if rank == 0:
+        unet_sd, ae_sd = load_fn()
+        with torch.no_grad():
+            reload_model(model, unet_sd)
+            reload_model(autoencoder, ae_sd)
+        eng.load_state_dicts(unet_sd=model.state_dict(), ae_sd=autoencoder.state_dict())
+    if world > 1:
+        torch.cuda.synchronize(dev)
+        broadcast_blob(eng.weight_blob(), src=0)
+        torch.cuda.synchronize(dev)
+    eng.mark_weights_ready()
+    return eng

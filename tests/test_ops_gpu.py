@@ -184,12 +184,11 @@ def _window_attention_reference(qkv_nchw, table, heads, shift, ws=8):
     idx = rel[..., 0] * (2 * ws - 1) + rel[..., 1]
     attn = attn + table[idx.view(-1)].view(ws * ws, ws * ws, heads).permute(2, 0, 1).unsqueeze(0)
     if shift:
+        # reference quirk (swin_transformer.py:217-228): the (1,1,H,W) mask image is indexed [:, h, w, :], so the
+        # region id only depends on the row band
         img = torch.zeros(1, 1, H, W)
-        cnt = 0
-        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
-            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
-                img[:, :, hs, wsl] = cnt
-                cnt += 1
+        for cnt, rows in zip((6, 7, 8), (slice(0, -ws), slice(-ws, -shift), slice(-shift, None))):
+            img[:, :, rows, :] = cnt
         mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws)
         mask = (mw.unsqueeze(1) - mw.unsqueeze(2) != 0).float() * -100.0
         nW = mask.shape[0]

@@ -1,0 +1,107 @@
+"""The oracle (oracle/resshift_oracle.py) against the committed golden outputs of the reference itself
+(tests/golden/reference_outputs.npz, produced by oracle/make_golden.py from /root/reference), plus — where the
+reference tree is present — a live re-check against the unmodified reference modules."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import ref_import, resshift_oracle as oc
+
+torch.set_grad_enabled(False)
+
+
+def test_schedule_known_answers():
+    """SURVEY.md §8c known-answer vector + the reference's own tables stored in the golden file."""
+    _, _, dp = H.realsr_params()
+    s = oc.Schedule(dp)
+    kat = [0.02, 0.11716508, 0.17630456, 0.23362892, 0.29157413, 0.35100928, 0.41235614, 0.47585773, 0.54167168, 0.60990993,
+           0.68065802, 0.75398526, 0.82995066, 0.90860639, 0.99]
+    assert np.allclose(s.sqrt_etas, kat, atol=1e-8)
+    assert np.allclose(s.posterior_mean_coef1[1:4], [0.02913826, 0.44164095, 0.56947397], atol=1e-8)
+    assert np.allclose(s.posterior_variance[1:3], [0.00155338, 0.03065984], atol=1e-8)
+    assert s.timestep_map == list(range(15))
+    g = H.golden()
+    for k in ("sqrt_etas", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped"):
+        assert np.array_equal(getattr(s, k), g[f"sched/realsr_swinunet_realesrgan256/{k}"])
+
+
+def test_product_schedule_matches_reference_tables():
+    from resshift_amd.gaussian_diffusion import create_gaussian_diffusion
+
+    g = H.golden()
+    for cname in ("realsr_swinunet_realesrgan256", "realsr_swinunet_realesrgan256_journal"):
+        dp = H.to_plain(H.load_config(cname))["diffusion"]["params"]
+        d = create_gaussian_diffusion(**dp)
+        for k in ("sqrt_etas", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped"):
+            assert np.array_equal(getattr(d, k), g[f"sched/{cname}/{k}"]), (cname, k)
+
+
+@pytest.mark.parametrize("tag", list(H.CASES))
+def test_oracle_tiny_cases_match_reference_outputs(tag):
+    up, ap, dp, with_mask = H.CASES[tag]
+    g = H.golden()
+    usd, asd = H.weights(up, ap)
+    y, noises, mask = H.case_inputs(up, ap, dp, with_mask)
+    x, t = noises[1] * 1.3, torch.tensor([2, 2])
+    kw = {"lq": y}
+    if with_mask:
+        kw["mask"] = mask
+    assert H.rel_err(oc.unet_forward(usd, up, x, t, **kw), torch.from_numpy(g[f"{tag}/unet"])) < 2e-5
+    img = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).random((2, 3, 64, 64), dtype=np.float32) * 2 - 1)
+    assert H.rel_err(oc.vq_encode(asd, ap, img), torch.from_numpy(g[f"{tag}/encode"])) < 2e-5
+    d, idx = oc.vq_decode(asd, ap, noises[2] * 0.8, return_indices=True)
+    assert H.rel_err(d, torch.from_numpy(g[f"{tag}/decode"])) < 2e-5
+    assert np.array_equal(idx.numpy().astype(np.int32), g[f"{tag}/decode_idx"])
+    out, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    assert H.rel_err(aux["z_final"], torch.from_numpy(g[f"{tag}/sample_z"])) < 5e-5
+    assert (aux["indices"].numpy() == g[f"{tag}/sample_idx"]).mean() >= 0.995
+    assert H.psnr(out.clamp(-1, 1), torch.from_numpy(g[f"{tag}/sample"]).clamp(-1, 1)) > 70.0
+
+
+def test_oracle_full_size_realsr_matches_reference_output():
+    """64x64 -> 256x256, 15 steps, B=1: the headline configuration at full size."""
+    up, ap, dp = H.realsr_params()
+    g = H.golden()
+    usd, asd = H.weights(up, ap)
+    y, noises, _ = H.synth.synthetic_inputs(H.SEED_X, 1, 64, 64, 3, 64, 64, dp["steps"])
+    assert H.rel_err(oc.unet_forward(usd, up, noises[1] * 1.3, torch.tensor([7]), lq=y), torch.from_numpy(g["realsr/unet"])) < 2e-5
+    out, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, return_aux=True)
+    assert H.rel_err(aux["z_final"], torch.from_numpy(g["realsr/sample_z"])) < 1e-4
+    agree = (aux["indices"].numpy() == g["realsr/sample_idx"].astype(np.int64)).mean()
+    assert agree >= 0.995, agree
+    assert H.psnr(out.clamp(-1, 1), torch.from_numpy(g["realsr/sample"].astype(np.float32)).clamp(-1, 1)) > 60.0
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_oracle_live_against_reference_modules():
+    U, V, create = ref_import.load()
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    um = U(**up).eval()
+    um.load_state_dict(usd, strict=True)
+    am = V(**ap).eval()
+    am.load_state_dict(asd, strict=True)
+    y, noises, _ = H.case_inputs(up, ap, dp, False)
+    x, t = noises[1] * 1.3, torch.tensor([3, 3])
+    assert torch.equal(oc.unet_forward(usd, up, x, t, lq=y), um(x, t, lq=y))
+    z = am.encode(torch.nn.functional.interpolate(y, scale_factor=4, mode="bicubic"))
+    assert H.rel_err(oc.vq_encode(asd, ap, torch.nn.functional.interpolate(y, scale_factor=4, mode="bicubic")), z) < 2e-5
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("cname", ["realsr_swinunet_realesrgan256", "faceir_gfpgan512_lpips", "inpaint_lama256_imagenet"])
+def test_spec_equals_reference_state_dict(cname):
+    """resshift_amd.spec must list exactly the reference's state_dict keys, shapes and order."""
+    import os
+
+    U, V, _ = ref_import.load()
+    ref_cfg = H.to_plain(H.load_config(os.path.join(ref_import.REF, "configs", cname + ".yaml")))
+    mine = H.to_plain(H.load_config(cname))
+    for sec in ("model", "diffusion", "autoencoder"):
+        assert ref_cfg[sec] == mine[sec], f"config digest drifted from the reference YAML: {cname}/{sec}"
+    m = U(**ref_cfg["model"]["params"])
+    spec, _ = H.unet_param_spec(mine["model"]["params"])
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == list(spec.items())
+    a = V(**ref_cfg["autoencoder"]["params"])
+    assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == list(H.ae_param_spec(mine["autoencoder"]["params"]).items())
