@@ -126,6 +126,12 @@ int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float 
 /* bytes of scratch arena currently allocated; number of kernel launches issued by the last call */
 size_t rs_arena_bytes(rs_engine* e);
 long long rs_last_launch_count(rs_engine* e);
+/* debug trace (tests only): when enabled, the next network call records named intermediate activations
+ * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
+int rs_debug_enable(rs_engine* e, int on);
+int rs_debug_count(rs_engine* e);
+int rs_debug_info(rs_engine* e, int i, char* name, int name_cap, int* dims_bchw);
+int rs_debug_fetch(rs_engine* e, int i, float* out_nchw_dev, void* stream);
 
 /* ---- op-level entry points (used by tests/ to check each kernel against torch on its own) ---- */
 /* NHWC conv / linear through the MFMA implicit GEMM or the direct kernels (auto-selected).

@@ -85,6 +85,10 @@ SIGNATURES = {
     "rs_axpbypcz": (_I, [_P, _P, _P, _P, _F, _F, _F, _LL, _P]),
     "rs_arena_bytes": (_SZ, [_P]),
     "rs_last_launch_count": (_LL, [_P]),
+    "rs_debug_enable": (_I, [_P, _I]),
+    "rs_debug_count": (_I, [_P]),
+    "rs_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int)]),
+    "rs_debug_fetch": (_I, [_P, _I, _P, _P]),
     "rs_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 18 + [_P]),
     "rs_op_gemm_nt": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "rs_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),

@@ -109,7 +109,11 @@ struct Exec {
     }
     void* raw(size_t bytes) { return arena->alloc(bytes); }
     size_t mark() const { return arena->off; }
-    void reset(size_t m) { arena->off = m; }
+    bool keep = false;  // debug trace: never recycle scratch so that every recorded view stays valid
+    std::vector<std::pair<std::string, View>>* trace = nullptr;
+    std::string prefix;
+    void reset(size_t m) { if (!keep) arena->off = m; }
+    void tr(const std::string& name, const View& v) { if (trace && !dry) trace->emplace_back(prefix + name, v); }
     void check(int rc, const char* what) {
         ++launches;
         if (rc != 0 && err == 0) { err = rc; g_err = std::string("launch failed: ") + what; }
@@ -127,6 +131,8 @@ struct rs_engine {
     std::string build_err;
     Arena arena;
     long long last_launches = 0;
+    bool debug = false;
+    std::vector<std::pair<std::string, View>> trace;
     // UNet
     std::vector<UBlock> in_blocks, out_blocks;
     ResBlockW mid_res1, mid_res2; BasicLayerW mid_swin;
@@ -466,10 +472,13 @@ struct rs_engine {
         const size_t mk = ex.mark();
         View t1 = ex.T(X.B, X.H, X.W, X.C, X.dt);
         gn(ex, r.n1, X, t1, 1e-5f, RS_ACT_SILU);
+        ex.tr("gn1", t1);
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
         conv3(ex, r.c1, t1, h1);
+        ex.tr("conv1", h1);
         View t2 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
         gn(ex, r.n2, h1, t2, 1e-5f, RS_ACT_SILU, film_row ? film_row + r.film_off : nullptr);
+        ex.tr("gn2film", t2);
         if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
             conv1(ex, r.skip, X, sk);
@@ -503,11 +512,15 @@ struct rs_engine {
         const int E = b.E, heads = cfg.unet.num_heads;
         View e = ex.T(X.B, X.H, X.W, E, X.dt);
         conv1(ex, b.embed, X, e);
+        ex.tr("embed", e);
+        int bi = 0;
         for (const SwinBlockW& s : b.blocks) {
+            const std::string bp = "blk" + std::to_string(bi++) + ".";
             View n = ex.T(X.B, X.H, X.W, E, X.dt);
             gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE);
             View qkv = ex.T(X.B, X.H, X.W, 3 * E, X.dt);
             conv1(ex, s.qkv, n, qkv);
+            ex.tr(bp + "qkv", qkv);
             View a = ex.T(X.B, X.H, X.W, E, X.dt);
             if (!ex.dry) {
                 WinAttnParams p{};
@@ -515,14 +528,17 @@ struct rs_engine {
                 p.shift = s.shift; p.ldq = qkv.ld; p.ldo = a.ld; p.scale = 1.0f / std::sqrt((float)(E / heads));
                 ex.check(rs_win_attn_launch(&p, X.dt, ex.st), "win_attn");
             }
+            ex.tr(bp + "attn", a);
             View e2 = ex.T(X.B, X.H, X.W, E, X.dt);
             conv1(ex, s.proj, a, e2, &e);
+            ex.tr(bp + "proj", e2);
             View n2 = ex.T(X.B, X.H, X.W, E, X.dt);
             gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE);
             View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
             conv1(ex, s.fc1, n2, f, nullptr, RS_ACT_GELU);
             View e3 = ex.T(X.B, X.H, X.W, E, X.dt);
             conv1(ex, s.fc2, f, e3, &e2);
+            ex.tr(bp + "out", e3);
             e = e3;
         }
         conv1(ex, b.unembed, e, Y);
@@ -645,6 +661,7 @@ struct rs_engine {
             }
             ex.reset(mk);
             h = y0;
+            ex.tr("in.0", h);
         }
         // ---- input blocks
         for (int i = 1; i < n_in; ++i) {
@@ -653,12 +670,21 @@ struct rs_engine {
             View y = skip_view(i);
             if (b.has_down) {
                 conv(ex, b.conv, h, nullptr, y, 2, 1, 1, 1, 0, nullptr);
+                ex.tr("in." + std::to_string(i), y);
             } else if (b.has_swin) {
                 View r = ex.T(B, h.H, h.W, b.out_ch, dt);
+                ex.prefix = "in." + std::to_string(i) + ".res.";
                 resblock(ex, b.res, h, r, film);
+                ex.prefix = "in." + std::to_string(i) + ".swin.";
                 basiclayer(ex, b.swin, r, y);
+                ex.prefix.clear();
+                ex.tr("in." + std::to_string(i) + ".res", r);
+                ex.tr("in." + std::to_string(i), y);
             } else {
+                ex.prefix = "in." + std::to_string(i) + ".res.";
                 resblock(ex, b.res, h, y, film);
+                ex.prefix.clear();
+                ex.tr("in." + std::to_string(i), y);
             }
             ex.reset(mk);
             h = y;
@@ -668,9 +694,12 @@ struct rs_engine {
             const size_t mk = ex.mark();
             View r1 = ex.T(B, h.H, h.W, h.C, dt), r2 = ex.T(B, h.H, h.W, h.C, dt);
             resblock(ex, mid_res1, h, r1, film);
+            ex.tr("mid.res1", r1);
             basiclayer(ex, mid_swin, r1, r2);
+            ex.tr("mid.swin", r2);
             View y = cat[0].slice(0, h_ch[0]);
             resblock(ex, mid_res2, r2, y, film);
+            ex.tr("mid.res2", y);
             ex.reset(mk);
         }
         // ---- output blocks (unet.py:890-892)
@@ -702,6 +731,7 @@ struct rs_engine {
                 }
                 if (b.has_up) conv(ex, b.conv, cur, nullptr, y, 1, 1, 1, 2, 0, nullptr);  // nearest x2 folded into the conv
             }
+            ex.tr("out." + std::to_string(j), y);
             ex.reset(mk);
         }
         // ---- out head (unet.py:893-894)
@@ -809,7 +839,7 @@ struct rs_engine {
     // ---------------------------------------------------------------- run helper (dry sizing pass, then real pass)
     int run(hipStream_t st, const std::function<void(Exec&)>& fn) {
         if (!ready) return fail("weights are not ready (rs_pack_weights / rs_weights_ready not called)");
-        Exec d; d.st = st; d.arena = &arena; d.dry = true;
+        Exec d; d.st = st; d.arena = &arena; d.dry = true; d.keep = debug;
         arena.off = 0; arena.peak = 0;
         fn(d);
         const size_t need = arena.peak + 4096;
@@ -821,7 +851,8 @@ struct rs_engine {
             if (hipMalloc((void**)&arena.base, want) != hipSuccess) return fail("hipMalloc of scratch arena failed (" + std::to_string(want) + " bytes)");
             arena.cap = want;
         }
-        Exec r; r.st = st; r.arena = &arena; r.dry = false;
+        Exec r; r.st = st; r.arena = &arena; r.dry = false; r.keep = debug;
+        if (debug) { trace.clear(); r.trace = &trace; }
         arena.off = 0; arena.peak = 0;
         fn(r);
         last_launches = r.launches;
@@ -909,6 +940,22 @@ int rs_weights_ready(rs_engine* e) {
 }
 
 size_t rs_arena_bytes(rs_engine* e) { return e ? e->arena.cap : 0; }
+
+// ---- debug trace (tests only): record named intermediate activations of the next network call
+int rs_debug_enable(rs_engine* e, int on) { if (!e) return -1; e->debug = on != 0; e->trace.clear(); return 0; }
+int rs_debug_count(rs_engine* e) { return e ? (int)e->trace.size() : 0; }
+int rs_debug_info(rs_engine* e, int i, char* name, int cap, int* dims /* B,C,H,W */) {
+    if (!e || i < 0 || i >= (int)e->trace.size()) return -1;
+    const auto& t = e->trace[i];
+    snprintf(name, cap, "%s", t.first.c_str());
+    dims[0] = t.second.B; dims[1] = t.second.C; dims[2] = t.second.H; dims[3] = t.second.W;
+    return 0;
+}
+int rs_debug_fetch(rs_engine* e, int i, float* out_nchw, void* stream) {
+    if (!e || i < 0 || i >= (int)e->trace.size()) return -1;
+    const View& v = e->trace[i].second;
+    return rs_nhwc_to_nchw_launch(v.p, v.dt, out_nchw, v.B, v.C, v.H * v.W, v.ld, 0, (hipStream_t)stream);
+}
 long long rs_last_launch_count(rs_engine* e) { return e ? e->last_launches : 0; }
 
 int rs_unet_forward(rs_engine* e, const float* x, const int* t_host, const float* lq, const float* mask, float* out, int B, int H, int W,

@@ -171,7 +171,11 @@ __global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
         // region ids of calculate_mask (swin_transformer.py:214-236) on the shifted grid.  The reference indexes its
         // (1,1,H,W) mask image as [:, h, w, :], so its "h" slices hit the singleton dim and its "w" slices hit the ROW
         // axis: the effective region id is the row band only (pinned against the reference, oracle/make_golden.py).
-        rid[tid] = ys < p.H - WS ? 0 : (ys < p.H - p.shift ? 1 : 2);
+        // Second quirk: window_partition(img_mask) is followed by a further .permute(0,2,3,1) (:230), which swaps the
+        // row/column roles inside each window before flattening, so token (r,c) receives the label of position (c,r).
+        // Net effect: region(token i) = row band of (window_row*8 + token_column).
+        const int yq = wy * WS + (i & 7);
+        rid[tid] = yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2);
     }
     __syncthreads();
     float sc[NT];

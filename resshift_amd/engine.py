@@ -245,6 +245,22 @@ class Engine:
             return out, {"z_final": z_out, "indices": idx}
         return out
 
+    def debug_enable(self, on: bool = True):
+        self.lib.rs_debug_enable(self._h, int(on))
+
+    def debug_trace(self):
+        """name -> NCHW fp32 tensor for every activation recorded by the last call (debug_enable(True) first)."""
+        out = {}
+        for i in range(self.lib.rs_debug_count(self._h)):
+            name = C.create_string_buffer(128)
+            dims = (C.c_int * 4)()
+            self.lib.rs_debug_info(self._h, i, name, 128, dims)
+            t = torch.empty(dims[0], dims[1], dims[2], dims[3], device=self.device, dtype=torch.float32)
+            self._chk(self.lib.rs_debug_fetch(self._h, i, t.data_ptr(), self._stream()), "rs_debug_fetch")
+            out[name.value.decode()] = t
+        torch.cuda.synchronize(self.device)
+        return out
+
     def arena_bytes(self) -> int:
         return int(self.lib.rs_arena_bytes(self._h))
 

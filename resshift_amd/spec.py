@@ -234,6 +234,9 @@ def shift_attn_mask(H: int, W: int, ws: int, shift: int):
     img = torch.zeros(1, 1, H, W)
     for cnt, rows in zip((6, 7, 8), (slice(0, -ws), slice(-ws, -shift), slice(-shift, None))):
         img[:, :, rows, :] = cnt
-    mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws)
+    # ... and the partitioned windows [nW,ws,ws,1] are permuted (0,2,3,1) once more before flattening (:230),
+    # which transposes the token order inside each window.  Also reproduced as is.
+    mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws, ws, 1)
+    mw = mw.permute(0, 2, 3, 1).reshape(-1, ws * ws)
     m = mw.unsqueeze(1) - mw.unsqueeze(2)
     return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)

@@ -189,7 +189,10 @@ def _window_attention_reference(qkv_nchw, table, heads, shift, ws=8):
         img = torch.zeros(1, 1, H, W)
         for cnt, rows in zip((6, 7, 8), (slice(0, -ws), slice(-ws, -shift), slice(-shift, None))):
             img[:, :, rows, :] = cnt
-        mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws * ws)
+        # second quirk (:230): window_partition(...) output [nW,ws,ws,1] is permuted (0,2,3,1) once more before the
+        # flatten, which transposes the token order inside each window
+        mw = img.view(1, 1, H // ws, ws, W // ws, ws).permute(0, 2, 4, 3, 5, 1).reshape(-1, ws, ws, 1)
+        mw = mw.permute(0, 2, 3, 1).reshape(-1, ws * ws)
         mask = (mw.unsqueeze(1) - mw.unsqueeze(2) != 0).float() * -100.0
         nW = mask.shape[0]
         attn = (attn.view(-1, nW, heads, ws * ws, ws * ws) + mask[None, :, None]).view(-1, heads, ws * ws, ws * ws)
