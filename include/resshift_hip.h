@@ -126,6 +126,12 @@ int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float 
 /* bytes of scratch arena currently allocated; number of kernel launches issued by the last call */
 size_t rs_arena_bytes(rs_engine* e);
 long long rs_last_launch_count(rs_engine* e);
+/* profiling of the MFMA implicit-GEMM kernel family: when enabled every igemm launch of the next call is
+ * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[4] = {fp16-input igemm FLOPs,
+ * fp32-input igemm FLOPs, summed igemm kernel milliseconds, igemm launch count} of the last call
+ * (FLOP counts are always maintained; the time is 0 unless profiling was on). */
+int rs_profile_enable(rs_engine* e, int on);
+int rs_profile_get(rs_engine* e, double* out4);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
 int rs_debug_enable(rs_engine* e, int on);

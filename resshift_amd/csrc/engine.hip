@@ -118,6 +118,28 @@ struct Exec {
         ++launches;
         if (rc != 0 && err == 0) { err = rc; g_err = std::string("launch failed: ") + what; }
     }
+    // MFMA implicit-GEMM launches are the roofline-relevant kernel family: count their algorithmic FLOPs
+    // (2*M*N*K per batch entry, K = taps*Cin as in the usual conv FLOP count) and, when profiling is on, bracket
+    // every launch with hipEvents on the launch stream.
+    struct Prof { bool on = false; std::vector<hipEvent_t> ev; size_t used = 0; } * prof = nullptr;
+    double igemm_flops[2] = {0.0, 0.0};  // per input precision
+    long long igemm_launches = 0;
+    void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
+        igemm_flops[in_dt == RS_F16 ? 0 : 1] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
+        ++igemm_launches;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && prof->on) {
+            if (prof->used + 2 > prof->ev.size()) {
+                const size_t old = prof->ev.size();
+                prof->ev.resize(old + 1024);
+                for (size_t i = old; i < prof->ev.size(); ++i) (void)hipEventCreate(&prof->ev[i]);
+            }
+            e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
+            (void)hipEventRecord(e0, st);
+        }
+        check(rs_igemm_launch(&p, in_dt, out_dt, nz, st), what);
+        if (e1) (void)hipEventRecord(e1, st);
+    }
 };
 
 }  // namespace
@@ -131,6 +153,9 @@ struct rs_engine {
     std::string build_err;
     Arena arena;
     long long last_launches = 0;
+    Exec::Prof prof;
+    double last_flops[2] = {0.0, 0.0}, last_igemm_ms = 0.0;
+    long long last_igemm_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
     // UNet
@@ -445,7 +470,7 @@ struct rs_engine {
             p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
             p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32)"; return; }
-            ex.check(rs_igemm_launch(&p, x.dt, y.dt, 1, ex.st), "igemm");
+            ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
     }
     void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
@@ -583,7 +608,7 @@ struct rs_engine {
         p.x0 = A; p.w = Bm; p.bias = bias; p.y = y; p.C0 = K; p.ld0 = K; p.B = 1; p.Hs = M; p.Ws = 1; p.up = 1; p.Ho = M; p.Wo = 1;
         p.KH = 1; p.KW = 1; p.stride = 1; p.Cout = N; p.ldy = N; p.M = M; p.Ktot = K; p.out_scale = scale;
         p.bs_x0 = bsA; p.bs_w = bsB; p.bs_y = bsY;
-        ex.check(rs_igemm_launch(&p, in_dt, out_dt, nz, ex.st), "gemm_nt");
+        ex.igemm(p, in_dt, out_dt, nz, "gemm_nt");
     }
 
     // ---------------------------------------------------------------- FiLM cache
@@ -854,8 +879,19 @@ struct rs_engine {
         Exec r; r.st = st; r.arena = &arena; r.dry = false; r.keep = debug;
         if (debug) { trace.clear(); r.trace = &trace; }
         arena.off = 0; arena.peak = 0;
+        r.prof = &prof; prof.used = 0;
         fn(r);
         last_launches = r.launches;
+        last_flops[0] = r.igemm_flops[0]; last_flops[1] = r.igemm_flops[1]; last_igemm_launches = r.igemm_launches;
+        last_igemm_ms = 0.0;
+        if (prof.on && prof.used) {
+            (void)hipStreamSynchronize(st);
+            for (size_t i = 0; i + 1 < prof.used; i += 2) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
+                last_igemm_ms += ms;
+            }
+        }
         if (r.err) return r.err;
         return 0;
     }
@@ -940,6 +976,16 @@ int rs_weights_ready(rs_engine* e) {
 }
 
 size_t rs_arena_bytes(rs_engine* e) { return e ? e->arena.cap : 0; }
+
+// ---- profiling of the MFMA implicit-GEMM kernel family (bench.py roofline block)
+int rs_profile_enable(rs_engine* e, int on) { if (!e) return -1; e->prof.on = on != 0; return 0; }
+// out[0] = fp16-input igemm FLOPs of the last call, out[1] = fp32-input igemm FLOPs, out[2] = summed igemm kernel
+// time in ms (hipEvents on the launch stream; 0 unless profiling was enabled), out[3] = igemm launch count
+int rs_profile_get(rs_engine* e, double* out) {
+    if (!e || !out) return -1;
+    out[0] = e->last_flops[0]; out[1] = e->last_flops[1]; out[2] = e->last_igemm_ms; out[3] = (double)e->last_igemm_launches;
+    return 0;
+}
 
 // ---- debug trace (tests only): record named intermediate activations of the next network call
 int rs_debug_enable(rs_engine* e, int on) { if (!e) return -1; e->debug = on != 0; e->trace.clear(); return 0; }

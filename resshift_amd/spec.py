@@ -240,3 +240,35 @@ def shift_attn_mask(H: int, W: int, ws: int, shift: int):
     mw = mw.permute(0, 2, 3, 1).reshape(-1, ws * ws)
     m = mw.unsqueeze(1) - mw.unsqueeze(2)
     return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def random_state_dict(spec, seed: int = 0, buffers=(), window: int = 8):
+    """Random-init weights of the right shapes (fan-in scaled normals; every tensor non-zero, unlike the reference's
+    zero-initialised ResBlock tails) for benchmarking and smoke runs when no checkpoint is available."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith("relative_position_index"):
+            sd[name] = relative_position_index(window)
+        elif name.endswith("attn_mask"):
+            side = int(round(shape[0] ** 0.5)) * window
+            sd[name] = shift_attn_mask(side, side, window, window // 2)
+        elif name.endswith("relative_position_bias_table"):
+            sd[name] = torch.randn(shape, generator=g) * 0.5
+        elif name == "quantize.embedding.weight":
+            sd[name] = torch.randn(shape, generator=g) * 0.6
+        elif len(shape) == 1:
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g) if name.endswith(".weight") else 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            scale = fan_in ** -0.5
+            if ".emb_layers." in name:
+                scale *= 0.5
+            if name == "decoder.conv_out.weight":
+                scale *= 0.3
+            sd[name] = torch.randn(shape, generator=g) * scale
+    return sd

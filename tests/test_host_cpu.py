@@ -1,0 +1,204 @@
+"""CPU-only tests of the host side: C-ABI surface, config loading, state_dict layout, checkpoint ingestion semantics,
+sharding math and a world_size-2 gloo run of the weight-broadcast / sharding plumbing."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+
+ROOT = H.ROOT
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from resshift_amd import _lib, build
+
+    build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "resshift_hip.h")).read()
+    declared = set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rs_engine"}
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/resshift_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    _lib.load()
+    assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors of rs_config / rs_sample_args must have the C sizes (ints/floats/pointers, natural alignment)."""
+    from resshift_amd import _lib
+
+    L, S = _lib.RS_MAX_LEVELS, _lib.RS_MAX_STEPS
+    assert ctypes.sizeof(_lib.UNetConfig) == 4 * (5 + L + L + 1 + L + 4 + 1 + 3)
+    assert ctypes.sizeof(_lib.AEConfig) == 4 * (2 + L + L + 6 + 1 + L)
+    assert ctypes.sizeof(_lib.Config) == ctypes.sizeof(_lib.UNetConfig) + ctypes.sizeof(_lib.AEConfig) + 16
+    assert ctypes.sizeof(_lib.SampleArgs) == 6 * 8 + 5 * 4 + 4 * S * 4 + S * 4 + 2 * 4 + 2 * 4 + S * 4 + 4 + 8
+
+
+def test_engine_rejects_bad_configs_without_a_gpu():
+    from resshift_amd import _lib
+
+    lib = _lib.load()
+    cfg = _lib.Config()
+    assert not lib.rs_create(ctypes.byref(cfg))
+    assert "neither" in _lib.last_error()
+    cfg.has_unet = 1
+    cfg.enable_f16 = 1
+    cfg.unet.window_size = 7
+    assert not lib.rs_create(ctypes.byref(cfg))
+    assert "window_size" in _lib.last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    from resshift_amd import UNetModelSwin
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    up = H.CASES["tiny"][0]
+    m = UNetModelSwin(**up)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 16, 16), [0], lq=torch.zeros(1, 3, 16, 16))
+
+
+@pytest.mark.parametrize("name", ["realsr_swinunet_realesrgan256", "realsr_swinunet_realesrgan256_journal", "faceir_gfpgan512_lpips",
+                                  "inpaint_lama256_imagenet", "inpaint_lama256_face", "bicx4_swinunet_lpips", "realsr_realesrgan256_x2"])
+def test_config_digests_load_and_build_specs(name):
+    from resshift_amd.config import load_config
+
+    c = load_config(name)
+    assert c.model.target == "models.unet.UNetModelSwin"
+    assert c.model.params.out_channels == c.autoencoder.params.embed_dim  # `${autoencoder.params.embed_dim}` resolved
+    spec, buffers = H.unet_param_spec(c.model.params)
+    assert "input_blocks.0.0.weight" in spec and "out.2.bias" in spec
+    assert len([k for k in buffers if k.endswith("relative_position_index")]) == 18
+    H.ae_param_spec(c.autoencoder.params)
+
+
+def test_interpolation_resolution(tmp_path):
+    from resshift_amd.config import load_config
+
+    p = tmp_path / "c.yaml"
+    p.write_text("a:\n  b: 7\n  lst: [1, 2]\nc:\n  d: ${a.b}\n  e: ${c.d}\n  f: ${a.lst}\n")
+    c = load_config(str(p))
+    assert c.c.d == 7 and c.c.e == 7 and c.c.f == [1, 2]
+
+
+def test_known_key_counts_of_the_headline_config():
+    up, ap, _ = H.realsr_params()
+    spec, buffers = H.unet_param_spec(up)
+    assert len(spec) == 564  # SURVEY.md §5 (checkpoint/resume row): 564 UNet entries, 205 AE entries
+    assert len(H.ae_param_spec(ap)) == 205
+    n_params = sum(int(np.prod(s)) for k, s in spec.items() if k not in buffers)
+    assert n_params == 118593583  # BASELINE.md parameter count
+
+
+def test_shell_state_dict_matches_spec_and_reload_model_semantics():
+    from resshift_amd import UNetModelSwin, VQModelTorch
+    from resshift_amd.sampler import reload_model
+
+    up, ap, _, _ = H.CASES["tiny_fe"]
+    um, am = UNetModelSwin(**up), VQModelTorch(**ap)
+    spec, buffers = H.unet_param_spec(up)
+    assert [(k, tuple(v.shape)) for k, v in um.state_dict().items()] == list(spec.items())
+    assert [(k, tuple(v.shape)) for k, v in am.state_dict().items()] == list(H.ae_param_spec(ap).items())
+    assert {k for k, v in um.state_dict().items() if v.dtype != torch.float32} == {k for k in buffers if k.endswith("relative_position_index")}
+    usd, _ = H.weights(up, ap)
+    reload_model(um, {"module._orig_mod." + k: v for k, v in usd.items()})  # DDP + torch.compile prefixes (util_net.py:86-98)
+    for k, v in um.state_dict().items():
+        assert torch.equal(v, usd[k]), k
+    bad = dict(usd)
+    bad.pop("out.2.bias")
+    with pytest.raises(AssertionError):
+        reload_model(um, bad)
+
+
+def test_instantiate_from_config_maps_reference_targets():
+    from resshift_amd.sampler import instantiate_from_config
+
+    _, _, dp = H.realsr_params()
+    d = instantiate_from_config({"target": "models.script_util.create_gaussian_diffusion", "params": dp})
+    assert d.num_timesteps == 15 and d.timestep_map == list(range(15))
+    t = d.step_tables()
+    assert t["coef1"].dtype == np.float32 and t["coef1"][0] == 0.0 and abs(t["coef2"][0] - 1.0) < 1e-7
+    with pytest.raises(NotImplementedError):
+        instantiate_from_config({"target": "trainer.TrainerDifIR", "params": {}})
+
+
+@pytest.mark.parametrize("n,world", [(32, 1), (32, 8), (33, 8), (5, 8), (0, 4), (256, 8), (7, 2)])
+def test_shard_bounds_partition(n, world):
+    from resshift_amd.sharding import shard_bounds
+
+    pieces = [shard_bounds(n, r, world) for r in range(world)]
+    cover = []
+    for lo, hi in pieces:
+        assert 0 <= lo <= hi <= n
+        cover += list(range(lo, hi))
+    assert cover == list(range(n))                      # disjoint, ordered, complete
+    micro = -(-n // world) if n else 0
+    assert all(hi - lo <= micro for lo, hi in pieces)   # sampler.py:274-277: ceil(bs / num_gpus) per rank
+
+
+def test_shard_noise_is_a_slice_of_the_global_draw():
+    from resshift_amd.sharding import shard_batch, shard_noise
+
+    noise = torch.arange(3 * 10 * 2).float().view(3, 10, 2, 1, 1)
+    parts = [shard_noise(noise, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat(parts, 1), noise)
+    y = torch.arange(10).float().view(10, 1)
+    assert torch.equal(torch.cat([shard_batch(y, r, 4) for r in range(4)], 0), y)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    from resshift_amd import sharding
+
+    w, r = sharding.init_distributed()  # gloo on a GPU-less host
+    assert (w, r) == (world, rank) and dist.get_backend() == "gloo"
+    # 1. the packed-weight blob: rank 0 owns the content, everybody ends up with it after ONE broadcast
+    blob = torch.arange(4096, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
+    sharding.broadcast_blob(blob, src=0)
+    ok_blob = torch.equal(blob, torch.arange(4096, dtype=torch.int64).to(torch.uint8))
+    # 2. batch sharding + noise slicing + gather in global order
+    n = 5
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(n, 3, 4, 4, generator=g)
+    noise = torch.randn(3, n, 3, 4, 4, generator=g)
+    mine = sharding.shard_batch(y, rank, world)
+    nz = sharding.shard_noise(noise, rank, world)
+    local = mine * 2 + nz[0]  # stand-in for per-image work
+    full = sharding.gather_images(local, n, rank, world)
+    ok_gather = torch.allclose(full, y * 2 + noise[0])
+    sharding.barrier()
+    q.put((rank, ok_blob, ok_gather, tuple(mine.shape)))
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo_broadcast_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1] and res[0][2] and res[1][2]
+    assert res[0][3][0] == 3 and res[1][3][0] == 2  # ceil(5/2) then the remainder
