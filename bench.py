@@ -58,6 +58,15 @@ def policy_args(name: str, steps: int):
     raise SystemExit(f"unknown precision policy {name}")
 
 
+_T0 = time.time()
+
+
+def log(msg: str) -> None:
+    """progress on stderr (stdout carries only the JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,10 +97,12 @@ def main():
     def load_fn():
         return random_state_dict(uspec, seed=1), random_state_dict(ae_param_spec(aep), seed=2)
 
+    log("building models + packing weights")
     t0 = time.time()
     eng = sharding.build_engine_with_broadcast(model, ae, load_fn, rank, world)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
+    log(f"weights ready in {setup_s:.1f}s")
     diffusion = create_gaussian_diffusion(**dp)
     diffusion.adopt_engine(model, ae, eng)
     pu, pe, pd = policy_args(args.precision, steps)
@@ -107,8 +118,10 @@ def main():
         return eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, prec_unet=pu, prec_encode=pe,
                           prec_decode=pd)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         out = one_pass()
+        torch.cuda.synchronize()
+        log(f"warmup pass {i} done (arena {eng.arena_bytes() / 2**30:.2f} GiB)")
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
@@ -126,6 +139,7 @@ def main():
     assert torch.isfinite(out).all().item(), "non-finite output"
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    log(f"timed region done: {ms_per_step:.1f} ms/step, {value:.2f} img/s")
 
     # ---- roofline of the dominant kernel family (MFMA implicit GEMM), measured in a dedicated pass with hipEvents
     roofline = None
@@ -156,10 +170,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import resshift_oracle as oc  # checker / baseline only; never on the measured GPU path
 
-        torch.set_num_threads(os.cpu_count() or 1)
+        # use the cores this process may actually run on (cgroup/affinity aware), never more than torch's own default
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(usable, torch.get_num_threads(), 64)))
+        log(f"cpu baseline: oracle on {torch.get_num_threads()} threads")
         usd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         asd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
-        nb = 2
+        nb = 1
         yc = y[:nb].cpu()
         nz = [noise[k, :nb].cpu() for k in range(steps + 1)]
         t0 = time.perf_counter()
