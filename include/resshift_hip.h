@@ -146,6 +146,11 @@ int rs_debug_fetch(rs_engine* e, int i, float* out_nchw_dev, void* stream);
 int rs_op_conv2d(const void* x0, const void* x1, const float* w_ref_host, const float* bias_host, const void* res, void* y,
                  int B, int Hs, int Ws, int C0, int C1, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho,
                  int Wo, int up, int act, int in_prec, int out_prec, int force_direct, void* stream);
+/* timing probe for one implicit-GEMM conv shape: device-resident NHWC input, weights already packed [Cout][KH*KW*Cin]
+ * in the input precision; runs `reps` launches between two hipEvents and returns the average ms per launch. */
+int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bias_dev, const void* res, void* y, int B, int Hs,
+                       int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int Ho, int Wo, int up, int act, int in_prec,
+                       int out_prec, int reps, float* ms_out, void* stream);
 /* batched NT GEMM: y[z][m][n] = scale * sum_k a[z][m][k] * b[z][n][k]  (+bias[n]) */
 int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale,
                   int in_prec, int out_prec, void* stream);

@@ -31,6 +31,7 @@
 
 extern "C" {
 int rs_igemm_launch(const IGemmParams* p, int in_dt, int out_dt, int nz, hipStream_t st);
+int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_groupnorm_launch(const GNParams* p, int dt, int apply_slabs, hipStream_t st);
 int rs_win_attn_launch(const WinAttnParams* p, int dt, hipStream_t st);
@@ -451,8 +452,16 @@ struct rs_engine {
     // ---------------------------------------------------------------- ops
     void conv(Exec& ex, const ConvW& w, const View& x, const View* x1, const View& y, int stride, int pad_t, int pad_l, int up,
               int act, const View* res, float out_scale = 1.f) {
-        if (ex.dry) return;
         const int C1 = x1 ? x1->C : 0;
+        // split-K for launches that cannot fill the chip (8x8 / 16x16 UNet levels): fp32 slabs live in the arena
+        int splitk = 1;
+        float* partial = nullptr;
+        if (!w.direct) {
+            const int M = y.B * y.H * y.W;
+            splitk = rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * (x.C + C1), x.dt);
+            if (splitk > 1) partial = (float*)ex.raw((size_t)splitk * M * w.Cout * sizeof(float));
+        }
+        if (ex.dry) return;
         if (w.direct) {
             DirectConvParams p{};
             p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = w.wd; p.bias = w.bias; p.y = y.p;
@@ -469,6 +478,7 @@ struct rs_engine {
             p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = up; p.Ho = y.H; p.Wo = y.W; p.KH = w.KH; p.KW = w.KW;
             p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
             p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
+            p.splitk = splitk; p.partial = partial;
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
@@ -1167,12 +1177,46 @@ int rs_op_conv2d(const void* x0, const void* x1, const float* w_ref_host, const 
         p.x0 = x0; p.x1 = x1; p.w = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = C0; p.C1 = C1; p.ld0 = C0; p.ld1 = C1;
         p.B = B; p.Hs = Hs; p.Ws = Ws; p.up = up; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
         p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * Ho * Wo; p.Ktot = (int)K; p.act = act; p.out_scale = 1.f;
+        p.splitk = rs_igemm_splitk_plan(p.M, Cout, (int)K, in_prec);
+        float* part = nullptr;
+        if (p.splitk > 1) { (void)hipMalloc((void**)&part, (size_t)p.splitk * p.M * Cout * sizeof(float)); p.partial = part; }
         rc = rs_igemm_launch(&p, in_prec, out_prec, 1, st);
         if (rc) fail("igemm launch rejected the shape");
+        (void)hipStreamSynchronize(st);
+        if (part) (void)hipFree(part);
     }
     (void)hipStreamSynchronize(st);
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);
+    return rc;
+}
+
+// micro-benchmark of one implicit-GEMM conv shape (random device data is supplied by the caller): `reps` launches
+// bracketed by hipEvents on the stream; returns the average milliseconds per launch in *ms_out.
+int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bias_dev, const void* res, void* y, int B, int Hs, int Ws,
+                       int Cin, int Cout, int KH, int KW, int stride, int pad, int Ho, int Wo, int up, int act, int in_prec, int out_prec,
+                       int reps, float* ms_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    IGemmParams p{};
+    p.x0 = x0; p.w = w_packed_dev; p.bias = bias_dev; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin;
+    p.B = B; p.Hs = Hs; p.Ws = Ws; p.up = up; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad; p.pad_l = pad;
+    p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * Ho * Wo; p.Ktot = KH * KW * Cin; p.act = act; p.out_scale = 1.f;
+    p.splitk = rs_igemm_splitk_plan(p.M, Cout, p.Ktot, in_prec);
+    float* part = nullptr;
+    if (p.splitk > 1) { (void)hipMalloc((void**)&part, (size_t)p.splitk * p.M * Cout * sizeof(float)); p.partial = part; }
+    int rc = rs_igemm_launch(&p, in_prec, out_prec, 1, st);  // warm-up
+    if (rc) return fail("igemm launch rejected the shape");
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i) rc |= rs_igemm_launch(&p, in_prec, out_prec, 1, st);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms / (float)std::max(1, reps);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (part) (void)hipFree(part);
     return rc;
 }
 

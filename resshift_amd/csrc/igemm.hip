@@ -10,98 +10,23 @@
 //     NHWC source(s) with tap / channel arithmetic (zero fill outside the image, optional
 //     nearest-x2 upsample folded into the address, optional second source = channel concat).
 //   * The weight tile is the MFMA "A" operand and the pixel tile the "B" operand, so each
-//     lane ends up holding 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+//     lane ends up holding 4 consecutive output channels of one pixel.
 //   * Tile: BP pixels x BC channels x 128 bytes of K per stage, 256 threads = 4 waves (2x2),
 //     LDS double buffered, one barrier per K stage, XOR-swizzled 16-byte chunks so that the
 //     ds_read_b128 fragment reads are (at most 2-way) conflict free.
 //   * f16 storage -> v_mfma_f32_16x16x32_f16; f32 storage -> v_mfma_f32_16x16x4_f32 (exact fp32).
-#include "common.h"
+//   * Workgroup -> tile map is XCD aware: the 8 XCDs (private L2s) each get a contiguous run of
+//     tiles, channel tiles of one pixel tile are adjacent, so the gathered X rows are L2 hits.
+//   * Epilogue: scale, bias, GELU, residual in fp32 registers; fp16 results are transposed through
+//     LDS so that every lane stores 16 contiguous bytes (full 128..192-byte pixel rows per wave).
+//   * Split-K (grid.z) for launches with too few tiles to fill 256 CUs: fp32 partial slabs + a
+//     deterministic reduce kernel that applies the same epilogue.
+#include "igemm_common.h"
+#include <algorithm>
 
 namespace {
 
-template <typename T> struct MfmaOps;
-
-template <> struct MfmaOps<f16> {
-    static constexpr int CH = 8;  // elements per 16-byte chunk
-    // one K stage = 8 chunks = 64 halfs = 2 MFMA k-steps of 32
-    template <int FC, int FP>
-    static __device__ __forceinline__ void stage(const char* ws, const char* xs, int wrow0, int xrow0, int lr, int lg,
-                                                 f32x4 (&acc)[FC][FP]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 4 + lg;
-            f16x8 a[FC], b[FP];
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const int r = wrow0 + i * 16 + lr;
-                a[i] = *(const f16x8*)(ws + r * 128 + ((chunk ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int r = xrow0 + j * 16 + lr;
-                b[j] = *(const f16x8*)(xs + r * 128 + ((chunk ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-};
-
-template <> struct MfmaOps<float> {
-    static constexpr int CH = 4;
-    // one K stage = 8 chunks = 32 floats.  Lane group lg reads chunk ss*4+lg (4 floats) and feeds
-    // element s to MFMA step s: the k permutation is identical for both operands, so the sum is exact.
-    template <int FC, int FP>
-    static __device__ __forceinline__ void stage(const char* ws, const char* xs, int wrow0, int xrow0, int lr, int lg,
-                                                 f32x4 (&acc)[FC][FP]) {
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            const int chunk = ss * 4 + lg;
-            f32x4 a[FC], b[FP];
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const int r = wrow0 + i * 16 + lr;
-                a[i] = *(const f32x4*)(ws + r * 128 + ((chunk ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int r = xrow0 + j * 16 + lr;
-                b[j] = *(const f32x4*)(xs + r * 128 + ((chunk ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < FC; ++i)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        }
-    }
-};
-
-template <typename TO> struct Out4;
-template <> struct Out4<f16> {
-    static __device__ __forceinline__ void load(const f16* p, float (&v)[4]) {
-        f16x4 t = *(const f16x4*)p;
-        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
-    }
-    static __device__ __forceinline__ void store(f16* p, const float (&v)[4]) {
-        f16x4 t; t[0] = (f16)v[0]; t[1] = (f16)v[1]; t[2] = (f16)v[2]; t[3] = (f16)v[3];
-        *(f16x4*)p = t;
-    }
-};
-template <> struct Out4<float> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-        f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-    }
-    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
-        f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
-        *(f32x4*)p = t;
-    }
-};
+using namespace igemm_detail;
 
 template <typename TI, typename TO, int BP, int BC>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
@@ -125,13 +50,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int lr = lane & 15, lg = lane >> 4;
     const int wp = wave & 1, wc = wave >> 1;
 
-    const int m0 = blockIdx.x * BP;
-    const int n0 = blockIdx.y * BC;
+    const int nby = (p.Cout + BC - 1) / BC;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / nby) * BP;
+    const int n0 = (tile % nby) * BC;
     const long long z = blockIdx.z;
+    const bool split = p.splitk > 1;
 
-    const TI* x0 = (const TI*)p.x0 + z * p.bs_x0;
+    const TI* x0 = (const TI*)p.x0 + (split ? 0 : z * p.bs_x0);
     const TI* x1 = (const TI*)p.x1;
-    const TI* w = (const TI*)p.w + z * p.bs_w;
+    const TI* w = (const TI*)p.w + (split ? 0 : z * p.bs_w);
 
     const int Ctot = p.C0 + p.C1;
     const int ntaps = p.KH * p.KW;
@@ -156,8 +84,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             pixbase[i] = -1; iy0[i] = 0; ix0[i] = 0;
         }
     }
+    // K range of this workgroup (split-K: grid.z slices the K stages)
+    const int nk_total = (p.Ktot + BK - 1) / BK;
+    int kt0 = 0, kt1 = nk_total;
+    if (split) {
+        const int per = (nk_total + p.splitk - 1) / p.splitk;
+        kt0 = min(nk_total, (int)z * per);
+        kt1 = min(nk_total, kt0 + per);
+    }
     // K position of this thread's chunk
-    int kk = kc * CH;              // absolute k of the chunk
+    int kk = kt0 * BK + kc * CH;   // absolute k of the chunk
     int tap = kk / Ctot;
     int cc = kk - tap * Ctot;
 
@@ -214,61 +150,185 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.Ktot + BK - 1) / BK;
-    gload();
-    lds_write(0);
+    if (kt0 < kt1) {
+        gload();
+        lds_write(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) { advance(); gload(); }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) { advance(); gload(); }
         MfmaOps<TI>::template stage<FC, FP>(ws_base + cur * BC * 128, xs_base + cur * BP * 128, wc * (BC / 2),
                                             wp * (BP / 2), lr, lg, acc);
-        if (kt + 1 < nk) lds_write(cur ^ 1);
+        if (kt + 1 < kt1) lds_write(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue: lane holds channels n..n+3 of pixel m for each fragment
+    // ---------------------------------------------------------------- epilogue
+    // lane holds channels n..n+3 of pixel m for each fragment
+    if (split) {
+        // raw fp32 partial sums; scale / bias / activation / residual are applied by splitk_reduce_kernel
+        float* part = p.partial + z * (long long)p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / 2) + j * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (n >= p.Cout) continue;
+                float* pp = part + (long long)m * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *(f32x4*)pp = acc[i][j];
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.Cout; ++r) pp[r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
     TO* y = (TO*)p.y + z * p.bs_y;
     const TO* res = p.res ? (const TO*)p.res + z * p.bs_res : nullptr;
-    const bool vec_ok = ((p.ldy & 3) == 0) && (!res || (p.ldres & 3) == 0);
+    const bool res_vec = res && (p.ldres & 3) == 0;
+    if constexpr (sizeof(TO) == 2) {
+        // fp16: finish the math in registers, transpose the wave's (BP/2 x BC/2) tile through LDS, store 16 B per lane
+        constexpr int ROWB = (BC / 2) * 2 + 16;  // padded row pitch in bytes
+        char* stg = smem + wave * (BP / 2) * ROWB;
 #pragma unroll
-    for (int j = 0; j < FP; ++j) {
-        const int m = m0 + wp * (BP / 2) + j * 16 + lr;
-        if (m >= p.M) continue;
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / 2) + j * 16 + lr;
 #pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-            if (n >= p.Cout) continue;
-            float v[4];
+            for (int i = 0; i < FC; ++i) {
+                const int nl = i * 16 + lg * 4;
+                const int n = n0 + wc * (BC / 2) + nl;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = acc[i][j][r] * p.out_scale;
-                if (p.bias && n + r < p.Cout) t += p.bias[n + r];
-                v[r] = rs_apply_act(t, p.act);
-            }
-            TO* yp = y + (long long)m * p.ldy + n;
-            if (n + 3 < p.Cout && vec_ok) {
-                if (res) {
-                    float rv[4];
-                    Out4<TO>::load(res + (long long)m * p.ldres + n, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] * p.out_scale;
+                    if (p.bias && n + r < p.Cout) t += p.bias[n + r];
+                    v[r] = epi_act<TO>(t, p.act);
                 }
-                Out4<TO>::store(yp, v);
+                if (res && m < p.M && n < p.Cout) {
+                    if (res_vec && n + 3 < p.Cout) {
+                        float rv[4];
+                        Out4<TO>::load(res + (long long)m * p.ldres + n, rv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += (float)res[(long long)m * p.ldres + n + r];
+                    }
+                }
+                f16x4 h; h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
+                *(f16x4*)(stg + (j * 16 + lr) * ROWB + nl * 2) = h;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = (BC / 2) / 8;           // 16-byte chunks per row of the wave tile
+        constexpr int NITEM = (BP / 2) * CPR;
+        const bool vec_ok = (p.ldy & 7) == 0;
+        for (int idx = lane; idx < NITEM; idx += 64) {
+            const int row = idx / CPR, c8 = idx - row * CPR;
+            const int m = m0 + wp * (BP / 2) + row;
+            const int n = n0 + wc * (BC / 2) + c8 * 8;
+            if (m >= p.M || n >= p.Cout) continue;
+            const uint4 v = *(const uint4*)(stg + row * ROWB + c8 * 16);
+            TO* yp = y + (long long)m * p.ldy + n;
+            if (vec_ok && n + 7 < p.Cout) {
+                *(uint4*)yp = v;
             } else {
-                for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
-                    float t = v[r];
-                    if (res) t += (float)res[(long long)m * p.ldres + n + r];
-                    yp[r] = (TO)t;
+                const f16* hv = (const f16*)&v;
+                for (int r = 0; r < 8 && n + r < p.Cout; ++r) yp[r] = (TO)hv[r];
+            }
+        }
+    } else {
+        const bool vec_ok = ((p.ldy & 3) == 0);
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / 2) + j * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (n >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] * p.out_scale;
+                    if (p.bias && n + r < p.Cout) t += p.bias[n + r];
+                    v[r] = epi_act<TO>(t, p.act);
+                }
+                TO* yp = y + (long long)m * p.ldy + n;
+                if (n + 3 < p.Cout && vec_ok && (!res || res_vec)) {
+                    if (res) {
+                        float rv[4];
+                        Out4<TO>::load(res + (long long)m * p.ldres + n, rv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    }
+                    Out4<TO>::store(yp, v);
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+                        float t = v[r];
+                        if (res) t += (float)res[(long long)m * p.ldres + n + r];
+                        yp[r] = (TO)t;
+                    }
                 }
             }
         }
     }
 }
 
+// y[m][n] = act(scale * sum_z partial[z][m][n] + bias[n]) + res[m][n]; fixed summation order -> deterministic
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
+    const long long nq = (long long)p.M * (p.Cout >> 2);  // quads of 4 channels (Cout % 4 == 0 is guaranteed by the planner)
+    const long long slab = (long long)p.M * p.Cout;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+        const long long m = q / (p.Cout >> 2);
+        const int n = (int)(q - m * (p.Cout >> 2)) * 4;
+        f32x4 s = *(const f32x4*)(p.partial + m * p.Cout + n);
+        for (int zz = 1; zz < p.splitk; ++zz) {
+            const f32x4 t = *(const f32x4*)(p.partial + zz * slab + m * p.Cout + n);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = s[r] * p.out_scale;
+            if (p.bias) t += p.bias[n + r];
+            v[r] = epi_act<TO>(t, p.act);
+        }
+        if (p.res) {
+            if ((p.ldres & 3) == 0) {
+                float rv[4];
+                Out4<TO>::load((const TO*)p.res + m * p.ldres + n, rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            } else {
+                for (int r = 0; r < 4; ++r) v[r] += (float)((const TO*)p.res)[m * p.ldres + n + r];
+            }
+        }
+        TO* yp = (TO*)p.y + m * p.ldy + n;
+        if ((p.ldy & 3) == 0) Out4<TO>::store(yp, v);
+        else for (int r = 0; r < 4; ++r) yp[r] = (TO)v[r];
+    }
+}
+
+void pick_tile(int M, int Cout, int& BP, int& BC) {
+    // channel-tile selection: the model's Cout values are multiples of 160, 192 or 128.
+    auto waste = [&](int bc) { return ((Cout + bc - 1) / bc) * bc - Cout; };
+    int best = 128, bw = waste(128);
+    if (waste(160) < bw) { best = 160; bw = waste(160); }
+    if (waste(192) < bw) { best = 192; bw = waste(192); }
+    if (Cout <= 64) best = 64;
+    BC = best;
+    BP = (M <= 64 * 48) ? 64 : 128;  // few pixels: use the 64-pixel tile to get more workgroups
+}
+
 template <typename TI, typename TO, int BP, int BC>
 hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
-    dim3 grid((p.M + BP - 1) / BP, (p.Cout + BC - 1) / BC, nz);
+    const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
+    dim3 grid(tiles, 1, p.splitk > 1 ? p.splitk : nz);
     const size_t lds = 2 * (BP + BC) * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -276,20 +336,20 @@ hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL((igemm_kernel<TI, TO, BP, BC>), grid, dim3(256), lds, st, p);
+    if (p.splitk > 1) {
+        const long long nq = (long long)p.M * (p.Cout >> 2);
+        const unsigned blocks = (unsigned)std::min<long long>((nq + 255) / 256, 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3(blocks), dim3(256), 0, st, p);
+    }
     return hipGetLastError();
 }
 
 template <typename TI, typename TO>
 hipError_t launch_t(const IGemmParams& p, int nz, hipStream_t st) {
-    // channel-tile selection: the model's Cout values are multiples of 160, 192 or 128.
-    const int n = p.Cout;
-    auto waste = [&](int bc) { return ((n + bc - 1) / bc) * bc - n; };
-    int best = 128, bw = waste(128);
-    if (waste(160) < bw) { best = 160; bw = waste(160); }
-    if (waste(192) < bw) { best = 192; bw = waste(192); }
-    if (n <= 64) best = 64;
-    const bool small_m = p.M <= 64 * 48;  // few pixels: use the 64-pixel tile to get more workgroups
-    switch (best) {
+    int BP, BC;
+    pick_tile(p.M, p.Cout, BP, BC);
+    const bool small_m = BP == 64;
+    switch (BC) {
         case 64: return small_m ? launch_cfg<TI, TO, 64, 64>(p, nz, st) : launch_cfg<TI, TO, 128, 64>(p, nz, st);
         case 160: return small_m ? launch_cfg<TI, TO, 64, 160>(p, nz, st) : launch_cfg<TI, TO, 128, 160>(p, nz, st);
         case 192: return small_m ? launch_cfg<TI, TO, 64, 192>(p, nz, st) : launch_cfg<TI, TO, 128, 192>(p, nz, st);
@@ -299,14 +359,38 @@ hipError_t launch_t(const IGemmParams& p, int nz, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int rs_igemm2_pick(int M, int Cout, int nz, int* BP, int* BC);
+extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, int BP, int BC, int nz, hipStream_t st);
+
+// Split-K planner: returns the number of K slices (1 = no split) for a single (non-batched) launch.  The caller owns the
+// fp32 workspace of splitk * M * Cout floats (IGemmParams::partial).
+extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
+    int BP, BC;
+    pick_tile(M, Cout, BP, BC);
+    const int tiles = ((M + BP - 1) / BP) * ((Cout + BC - 1) / BC);
+    const int bk = in_dt == RS_F16 ? 64 : 32;
+    const int nk = (Ktot + bk - 1) / bk;
+    if (tiles >= 200 || nk < 16 || (Cout & 3)) return 1;
+    int s = (512 + tiles - 1) / tiles;
+    s = std::min(s, 8);
+    s = std::min(s, nk / 8);
+    return std::max(s, 1);
+}
+
 // in_dt: storage type of x/w; out_dt: storage type of y/res.  Supported: (F16,F16) (F16,F32) (F32,F32).
 // Requirements: (C0+C1) and C0 multiples of the 16-byte chunk (8 halfs / 4 floats); ld0/ld1 likewise;
-// source base pointers 16-byte aligned.
+// source base pointers 16-byte aligned.  p.splitk > 1 requires nz == 1 and p.partial.
 extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int nz, hipStream_t st) {
-    const IGemmParams& p = *pp;
+    IGemmParams p = *pp;
     const int ch = in_dt == RS_F16 ? 8 : 4;
     if ((p.C0 % ch) || (p.C1 % ch) || (p.ld0 % ch) || (p.C1 && (p.ld1 % ch)) || p.M <= 0 || p.Cout <= 0) return -2;
     if (p.up != 1 && p.up != 2) return -2;
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
+    // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
+    static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
+    int bp2 = 0, bc2 = 0;
+    if (use_v2 && p.splitk == 1 && rs_igemm2_pick(p.M, p.Cout, nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
     hipError_t e;
     if (in_dt == RS_F16 && out_dt == RS_F16) e = launch_t<f16, f16>(p, nz, st);
     else if (in_dt == RS_F16 && out_dt == RS_F32) e = launch_t<f16, float>(p, nz, st);

@@ -1,0 +1,72 @@
+"""GPU micro-benchmark of the implicit-GEMM kernel on the real layer shapes of realsr_swinunet_realesrgan256 at B=32.
+
+    python scripts/igemm_bench.py [fp16|fp32] [reps]
+
+Prints ms / TFLOP/s per shape and the weighted total for one full sampling pass (counts = launches per pass).
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from resshift_amd import _lib  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+P = 0 if prec == "fp16" else 1
+dt = torch.float16 if P == 0 else torch.float32
+B = 32
+# name, H(out), Cin, Cout, k, stride, up, act, res, launches per pass (15 UNet forwards + AE)
+U = 15
+SHAPES = [
+    ("unet c3 160->160 @64", 64, 160, 160, 3, 1, 1, 0, 1, 7 * U),
+    ("unet c3 320->160 @64", 64, 320, 160, 3, 1, 1, 0, 0, 2 * U),
+    ("unet c3 480->160 @64", 64, 480, 160, 3, 1, 1, 0, 0, 1 * U),
+    ("unet up 320->320 @64", 64, 320, 320, 3, 1, 2, 0, 0, 1 * U),
+    ("unet c3 320->320 @32", 32, 320, 320, 3, 1, 1, 0, 1, 7 * U),
+    ("unet c3 640->320 @32", 32, 640, 320, 3, 1, 1, 0, 0, 2 * U),
+    ("unet c3 320->320 @16", 16, 320, 320, 3, 1, 1, 0, 1, 7 * U),
+    ("unet c3 640->320 @16", 16, 640, 320, 3, 1, 1, 0, 0, 2 * U),
+    ("unet c3 640->640 @8", 8, 640, 640, 3, 1, 1, 0, 1, 10 * U),
+    ("unet c3 1280->640 @8", 8, 1280, 640, 3, 1, 1, 0, 0, 2 * U),
+    ("swin fc1 192->768 @64", 64, 192, 768, 1, 1, 1, 1, 0, 4 * U),
+    ("swin fc2 768->192 @64", 64, 768, 192, 1, 1, 1, 0, 1, 4 * U),
+    ("swin qkv 192->576 @64", 64, 192, 576, 1, 1, 1, 0, 0, 4 * U),
+    ("swin proj 192->192 @64", 64, 192, 192, 1, 1, 1, 0, 1, 4 * U),
+    ("swin fc1 192->768 @32", 32, 192, 768, 1, 1, 1, 1, 0, 4 * U),
+    ("swin emb 160->192 @64", 64, 160, 192, 1, 1, 1, 0, 0, 2 * U),
+    ("unet skip 320->160 @64", 64, 320, 160, 1, 1, 1, 0, 0, 2 * U),
+    ("ae c3 512->512 @64", 64, 512, 512, 3, 1, 1, 0, 1, 17),
+    ("ae c3 128->128 @256", 256, 128, 128, 3, 1, 1, 0, 1, 9),
+    ("ae c3 256->256 @128", 128, 256, 256, 3, 1, 1, 0, 1, 8),
+    ("ae up 512->512 @128", 128, 512, 512, 3, 1, 2, 0, 0, 1),
+    ("ae up 256->256 @256", 256, 256, 256, 3, 1, 2, 0, 0, 1),
+    ("ae c3 512->256 @128", 128, 512, 256, 3, 1, 1, 0, 0, 1),
+    ("ae c3 256->128 @256", 256, 256, 128, 3, 1, 1, 0, 0, 1),
+    ("ae q 512->512 @64 (1x1)", 64, 512, 512, 1, 1, 1, 0, 0, 8),
+]
+lib = _lib.load()
+dev = torch.device("cuda:0")
+st = _lib.current_stream_ptr()
+tot_ms = tot_fl = 0.0
+print(f"{'shape':28s} {'M':>8s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TF/s':>8s} {'n/pass':>6s} {'ms/pass':>8s}")
+for name, Ho, Cin, Cout, k, stride, up, act, res, cnt in SHAPES:
+    Hs = Ho * stride // up
+    x = torch.randn(B, Hs, Hs, Cin, device=dev).to(dt)
+    w = (torch.randn(Cout, k * k * Cin, device=dev) / (k * k * Cin) ** 0.5).to(dt)
+    bias = torch.randn(Cout, device=dev)
+    y = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=dt)
+    r = torch.randn(B, Ho, Ho, Cout, device=dev).to(dt) if res else None
+    ms = C.c_float(0)
+    rc = lib.rs_op_conv2d_bench(x.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, Hs, Hs,
+                                Cin, Cout, k, k, stride, k // 2, Ho, Ho, up, act, P, P, reps, C.byref(ms), st)
+    assert rc == 0, _lib.last_error()
+    M, K = B * Ho * Ho, k * k * Cin
+    fl = 2.0 * M * Cout * K
+    print(f"{name:28s} {M:8d} {Cout:5d} {K:6d} {ms.value:8.3f} {fl / ms.value / 1e9:8.1f} {cnt:6d} {ms.value * cnt:8.2f}", flush=True)
+    tot_ms += ms.value * cnt
+    tot_fl += fl * cnt
+    del x, w, y, r
+print(f"weighted total: {tot_ms:.1f} ms/pass for {tot_fl / 1e12:.1f} TFLOP -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
