@@ -75,7 +75,7 @@ struct Blob {
 };
 
 struct ConvW {
-    int Cin = 0, Cout = 0, KH = 1, KW = 1;
+    int Cin = 0, CinP = 0, Cout = 0, KH = 1, KW = 1;
     void* wh = nullptr; void* wf = nullptr; float* wd = nullptr; float* bias = nullptr;
     bool direct = false;
 };
@@ -191,10 +191,16 @@ struct rs_engine {
             memcpy(dst, t->data.data(), n * sizeof(float));
         });
     }
-    ConvW add_conv(const std::string& prefix, int Cin, int Cout, int KH, int KW, bool has_bias = true) {
+    // Every conv runs on the MFMA implicit GEMM; input channels are zero-padded to a multiple of 8 (CinP) so that the
+    // 16-byte K chunks stay aligned (3/6-channel image and latent inputs become 8-channel tensors).  `force_direct`
+    // keeps the scalar kernel for the fp32-in/fp32-out 1x1 quant convs and for two-source convs whose first source is
+    // not chunk aligned.
+    ConvW add_conv(const std::string& prefix, int Cin, int Cout, int KH, int KW, bool has_bias = true, bool force_direct = false) {
         ConvW c; c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW;
-        c.direct = (Cin % 8 != 0) || (Cout <= 8) || (Cin < 32);
-        const size_t K = (size_t)KH * KW * Cin, n = K * Cout;
+        c.direct = force_direct;
+        c.CinP = c.direct ? Cin : (Cin + 7) / 8 * 8;
+        const int CinP = c.CinP;
+        const size_t K = (size_t)KH * KW * CinP, n = (size_t)KH * KW * Cin * Cout, np = K * Cout;
         const std::string wkey = prefix + ".weight";
         auto get = [&]() -> const float* {
             const HostTensor* t = find(wkey);
@@ -212,23 +218,24 @@ struct rs_engine {
                             o[((size_t)t * Cin + ci) * Cout + co] = w[((size_t)co * Cin + ci) * KH * KW + t];
             });
         } else {
+            // (the staging buffer is zero-initialised, so padded input channels keep zero weights)
             if (cfg.enable_f16)
-                c.wh = blob.add(n * 2, [&](char* dst) {
+                c.wh = blob.add(np * 2, [&](char* dst) {
                     const float* w = get(); if (!w) return;
                     f16* o = (f16*)dst;  // [Cout][K]
                     for (int co = 0; co < Cout; ++co)
                         for (int ci = 0; ci < Cin; ++ci)
                             for (int t = 0; t < KH * KW; ++t)
-                                o[(size_t)co * K + (size_t)t * Cin + ci] = (f16)w[((size_t)co * Cin + ci) * KH * KW + t];
+                                o[(size_t)co * K + (size_t)t * CinP + ci] = (f16)w[((size_t)co * Cin + ci) * KH * KW + t];
                 });
             if (cfg.enable_f32)
-                c.wf = blob.add(n * 4, [&](char* dst) {
+                c.wf = blob.add(np * 4, [&](char* dst) {
                     const float* w = get(); if (!w) return;
                     float* o = (float*)dst;
                     for (int co = 0; co < Cout; ++co)
                         for (int ci = 0; ci < Cin; ++ci)
                             for (int t = 0; t < KH * KW; ++t)
-                                o[(size_t)co * K + (size_t)t * Cin + ci] = w[((size_t)co * Cin + ci) * KH * KW + t];
+                                o[(size_t)co * K + (size_t)t * CinP + ci] = w[((size_t)co * Cin + ci) * KH * KW + t];
                 });
         }
         if (has_bias) c.bias = add_f32(prefix + ".bias", Cout);
@@ -320,7 +327,9 @@ struct rs_engine {
         const int input_ch = ch;
         {
             UBlock b; b.has_conv = true; b.level = 0; b.out_ch = ch;
-            b.conv = add_conv("input_blocks.0.0", u.in_channels + fe_out_ch, ch, 3, 3);
+            // with a feature extractor the conv reads two sources (x | features): both must be 16-byte chunk aligned
+            const bool two_src_unaligned = !fe_convs.empty() && (u.in_channels % 8 != 0);
+            b.conv = add_conv("input_blocks.0.0", u.in_channels + fe_out_ch, ch, 3, 3, true, two_src_unaligned);
             in_blocks.push_back(b);
         }
         std::vector<int> chans{ch};
@@ -414,9 +423,9 @@ struct rs_engine {
         enc_mid2 = add_resnet("encoder.mid.block_2", block_in, block_in);
         enc_norm = add_gn("encoder.norm_out", block_in);
         enc_out = add_conv("encoder.conv_out", block_in, a.z_channels, 3, 3);
-        quant_conv = add_conv("quant_conv", a.z_channels, a.embed_dim, 1, 1);
+        quant_conv = add_conv("quant_conv", a.z_channels, a.embed_dim, 1, 1, true, /*force_direct=*/true);  // fp32 in / fp32 out
         // Decoder (model.py:550-660)
-        post_quant_conv = add_conv("post_quant_conv", a.embed_dim, a.z_channels, 1, 1);
+        post_quant_conv = add_conv("post_quant_conv", a.embed_dim, a.z_channels, 1, 1, true, /*force_direct=*/true);  // fp32 VQ output in
         block_in = a.ch * a.ch_mult[a.n_levels - 1];
         dec_in = add_conv("decoder.conv_in", a.z_channels, block_in, 3, 3);
         dec_mid1 = add_resnet("decoder.mid.block_1", block_in, block_in);
@@ -462,6 +471,7 @@ struct rs_engine {
             if (splitk > 1) partial = (float*)ex.raw((size_t)splitk * M * w.Cout * sizeof(float));
         }
         if (ex.dry) return;
+        if (x.C + C1 != w.CinP) { if (!ex.err) { ex.err = -3; g_err = "conv input channels do not match the packed weights"; } return; }
         if (w.direct) {
             DirectConvParams p{};
             p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = w.wd; p.bias = w.bias; p.y = y.p;
@@ -482,6 +492,11 @@ struct rs_engine {
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
+    }
+    void zero(Exec& ex, const View& v) {
+        if (ex.dry) return;
+        const hipError_t e = hipMemsetAsync(v.p, 0, (size_t)v.B * v.H * v.W * v.ld * rs_dtype_size(v.dt), ex.st);
+        ex.check(e == hipSuccess ? 0 : -1, "memset");
     }
     void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
         conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res);
@@ -681,11 +696,13 @@ struct rs_engine {
             View y0 = skip_view(0);
             if (fe_convs.empty()) {
                 const int cl = fe_out_ch;  // 3 or 4 raw conditioning channels at latent resolution
-                View in0 = ex.T(B, H, W, Cz + cl, RS_F32);
+                // cat[x, lq(, mask)] as one channel-padded NHWC tensor in the working precision (6/7 -> 8 channels)
+                View in0 = ex.T(B, H, W, in_blocks[0].conv.CinP, dt);
                 if (!ex.dry) {
-                    ex.check(rs_nchw_to_nhwc_launch(x, in0.p, RS_F32, B, Cz, H * W, in0.ld, 0, xscale, ex.st), "x->nhwc");
-                    if (cl) ex.check(rs_nchw_to_nhwc_launch(lq_nchw, in0.p, RS_F32, B, 3, H * W, in0.ld, Cz, 1.f, ex.st), "lq->nhwc");
-                    if (cl == 4) ex.check(rs_nchw_to_nhwc_launch(mask_nchw, in0.p, RS_F32, B, 1, H * W, in0.ld, Cz + 3, 1.f, ex.st), "mask->nhwc");
+                    zero(ex, in0);
+                    ex.check(rs_nchw_to_nhwc_launch(x, in0.p, dt, B, Cz, H * W, in0.ld, 0, xscale, ex.st), "x->nhwc");
+                    if (cl) ex.check(rs_nchw_to_nhwc_launch(lq_nchw, in0.p, dt, B, 3, H * W, in0.ld, Cz, 1.f, ex.st), "lq->nhwc");
+                    if (cl == 4) ex.check(rs_nchw_to_nhwc_launch(mask_nchw, in0.p, dt, B, 1, H * W, in0.ld, Cz + 3, 1.f, ex.st), "mask->nhwc");
                 }
                 conv(ex, in_blocks[0].conv, in0, nullptr, y0, 1, 1, 1, 1, 0, nullptr);
             } else {
@@ -782,10 +799,11 @@ struct rs_engine {
     // feature_extractor(cat[lq, mask]) (unet.py:876-881, 693-702): Conv3x3 -> SiLU -> Downsample conv s2
     View feature_extract(Exec& ex, const float* lq, const float* mask, int B, int Hl, int Wl, int dt) {
         const int cin = cfg.unet.cond_mask ? 4 : 3;
-        View cur = ex.T(B, Hl, Wl, cin, RS_F32);
+        View cur = ex.T(B, Hl, Wl, fe_convs[0].CinP, dt);  // 3/4 -> 8 zero-padded channels
         if (!ex.dry) {
-            ex.check(rs_nchw_to_nhwc_launch(lq, cur.p, RS_F32, B, 3, Hl * Wl, cur.ld, 0, 1.f, ex.st), "lq->nhwc");
-            if (cin == 4) ex.check(rs_nchw_to_nhwc_launch(mask, cur.p, RS_F32, B, 1, Hl * Wl, cur.ld, 3, 1.f, ex.st), "mask->nhwc");
+            zero(ex, cur);
+            ex.check(rs_nchw_to_nhwc_launch(lq, cur.p, dt, B, 3, Hl * Wl, cur.ld, 0, 1.f, ex.st), "lq->nhwc");
+            if (cin == 4) ex.check(rs_nchw_to_nhwc_launch(mask, cur.p, dt, B, 1, Hl * Wl, cur.ld, 3, 1.f, ex.st), "mask->nhwc");
         }
         for (size_t s = 0; s < fe_convs.size(); ++s) {
             View a = ex.T(B, cur.H, cur.W, fe_convs[s].Cout, dt);
@@ -842,8 +860,9 @@ struct rs_engine {
             q = ex.T(B, h_, w_, a.embed_dim, RS_F32);
             if (!ex.dry) ex.check(rs_vq_launch((const float*)z.p, codebook, (float*)q.p, idx_out, (long long)B * h_ * w_, a.n_embed, a.embed_dim, ex.st), "vq");
         }
-        View pq = ex.T(B, h_, w_, a.z_channels, RS_F32);
-        conv(ex, post_quant_conv, q, nullptr, pq, 1, 0, 0, 1, 0, nullptr);
+        View pq = ex.T(B, h_, w_, dec_in.CinP, dt);  // z_channels zero-padded to the decoder conv_in's chunk size
+        zero(ex, pq);
+        conv(ex, post_quant_conv, q, nullptr, pq.slice(0, a.z_channels), 1, 0, 0, 1, 0, nullptr);
         View h = ex.T(B, h_, w_, dec_in.Cout, dt);
         conv(ex, dec_in, pq, nullptr, h, 1, 1, 1, 1, 0, nullptr);
         View m1 = ex.T(B, h.H, h.W, h.C, dt); resnet(ex, dec_mid1, h, m1);
@@ -1037,8 +1056,9 @@ int rs_vq_encode(rs_engine* e, const float* img, float* z, int B, int H, int W, 
     if (!e || !e->cfg.has_ae) return fail("engine has no autoencoder");
     hipStream_t st = (hipStream_t)stream;
     return e->run(st, [&](Exec& ex) {
-        View in = ex.T(B, H, W, e->cfg.ae.in_channels, RS_F32);
-        if (!ex.dry) ex.check(rs_nchw_to_nhwc_launch(img, in.p, RS_F32, B, e->cfg.ae.in_channels, H * W, in.ld, 0, 1.f, st), "img->nhwc");
+        View in = ex.T(B, H, W, e->enc_in.CinP, prec);  // RGB zero-padded to 8 channels in the working precision
+        e->zero(ex, in);
+        if (!ex.dry) ex.check(rs_nchw_to_nhwc_launch(img, in.p, prec, B, e->cfg.ae.in_channels, H * W, in.ld, 0, 1.f, st), "img->nhwc");
         e->encode_body(ex, in, z, prec);
     });
 }
@@ -1100,10 +1120,11 @@ int rs_sample(rs_engine* e, const rs_sample_args* a) {
         // encode_first_stage (gaussian_diffusion.py:500-515)
         {
             const size_t mk = ex.mark();
-            View in = ex.T(B, Hi, Wi, ae.in_channels, RS_F32);
+            View in = ex.T(B, Hi, Wi, e->enc_in.CinP, a->prec_encode);  // RGB zero-padded to 8 channels
+            e->zero(ex, in);
             if (!ex.dry) {
-                if (a->sf != 1) ex.check(rs_bicubic_launch(a->y, in.p, RS_F32, B, ae.in_channels, a->h, a->w, a->sf, in.ld, st), "bicubic");
-                else ex.check(rs_nchw_to_nhwc_launch(a->y, in.p, RS_F32, B, ae.in_channels, Hi * Wi, in.ld, 0, 1.f, st), "y->nhwc");
+                if (a->sf != 1) ex.check(rs_bicubic_launch(a->y, in.p, a->prec_encode, B, ae.in_channels, a->h, a->w, a->sf, in.ld, st), "bicubic");
+                else ex.check(rs_nchw_to_nhwc_launch(a->y, in.p, a->prec_encode, B, ae.in_channels, Hi * Wi, in.ld, 0, 1.f, st), "y->nhwc");
             }
             e->encode_body(ex, in, z_y, a->prec_encode);
             ex.reset(mk);
