@@ -93,7 +93,8 @@ struct GNParams {
 struct WinAttnParams {
     const void* qkv;      // [B,H,W,ldq]: feature f = which*E + head*32 + d (swin_transformer.py:121)
     void* out;            // [B,H,W,ldo]: feature head*32 + d
-    const float* bias_t;  // [heads][64 (key j)][64 (query i)] relative position bias, transposed
+    const float* bias_t;  // [heads][64 (key j)][64 (query i)] relative position bias, transposed (VALU kernel)
+    const float* bias_n;  // [heads][64 (query i)][64 (key j)] (MFMA kernel); may be null -> VALU kernel is used
     int B, H, W, heads, shift, ldq, ldo;
     float scale;
 };

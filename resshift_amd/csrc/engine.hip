@@ -81,7 +81,7 @@ struct ConvW {
 };
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResBlockW { GNW n1, n2; ConvW c1, c2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int film_off = -1; ConvW emb; };
-struct SwinBlockW { GNW n1, n2; ConvW qkv, proj, fc1, fc2; float* bias_t = nullptr; int shift = 0; };
+struct SwinBlockW { GNW n1, n2; ConvW qkv, proj, fc1, fc2; float* bias_t = nullptr; float* bias_n = nullptr; int shift = 0; };
 struct BasicLayerW { ConvW embed, unembed; std::vector<SwinBlockW> blocks; int C = 0, E = 0; };
 struct UBlock {
     bool has_conv = false, has_res = false, has_swin = false, has_down = false, has_up = false;
@@ -286,6 +286,17 @@ struct rs_engine {
                         for (int i = 0; i < 64; ++i) {
                             const int idx = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
                             o[((size_t)h * 64 + j) * 64 + i] = t->data[(size_t)idx * heads + h];
+                        }
+            });
+            s.bias_n = (float*)blob.add((size_t)heads * 64 * 64 * 4, [&, tkey, heads](char* dst) {
+                const HostTensor* t = find(tkey);
+                if (!t || (int)t->data.size() != 225 * heads) return;
+                float* o = (float*)dst;  // [h][i][j] for the MFMA window kernel
+                for (int h = 0; h < heads; ++h)
+                    for (int i = 0; i < 64; ++i)
+                        for (int j = 0; j < 64; ++j) {
+                            const int idx = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+                            o[((size_t)h * 64 + i) * 64 + j] = t->data[(size_t)idx * heads + h];
                         }
             });
             s.proj = add_conv(q + ".attn.proj", E, E, 1, 1);
@@ -574,7 +585,7 @@ struct rs_engine {
             View a = ex.T(X.B, X.H, X.W, E, X.dt);
             if (!ex.dry) {
                 WinAttnParams p{};
-                p.qkv = qkv.p; p.out = a.p; p.bias_t = s.bias_t; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads;
+                p.qkv = qkv.p; p.out = a.p; p.bias_t = s.bias_t; p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads;
                 p.shift = s.shift; p.ldq = qkv.ld; p.ldo = a.ld; p.scale = 1.0f / std::sqrt((float)(E / heads));
                 ex.check(rs_win_attn_launch(&p, X.dt, ex.st), "win_attn");
             }
@@ -1283,13 +1294,20 @@ int rs_op_window_attention(const void* qkv, void* out, const float* table_host, 
                 bt[((size_t)h * 64 + j) * 64 + i] = table_host[(size_t)idx * heads + h];
             }
     float* d = (float*)dev_copy(bt.data(), bt.size() * 4);
+    std::vector<float> bn(bt.size());
+    for (int h = 0; h < heads; ++h)
+        for (int i = 0; i < 64; ++i)
+            for (int j = 0; j < 64; ++j) bn[((size_t)h * 64 + i) * 64 + j] = bt[((size_t)h * 64 + j) * 64 + i];
+    float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
     WinAttnParams p{};
+    p.bias_n = dn;
     p.qkv = qkv; p.out = out; p.bias_t = d; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldq = 3 * heads * 32;
     p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
     const int rc = rs_win_attn_launch(&p, prec, st);
     if (rc) fail("window attention launch rejected the shape");
     (void)hipStreamSynchronize(st);
     (void)hipFree(d);
+    (void)hipFree(dn);
     return rc;
 }
 

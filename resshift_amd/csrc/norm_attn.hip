@@ -30,7 +30,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
     for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
     if (pp < PP) {
         const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + j * 8;
-        for (int pix = p0 + pp; pix < p1; pix += PP) {
+        // 4 independent 16-byte loads in flight per thread (the loop is latency-, not bandwidth-bound otherwise)
+        int pix = p0 + pp;
+        for (; pix + 3 * PP < p1; pix += 4 * PP) {
+            Vec8<T> v0, v1, v2, v3;
+            v0.load(x + (long long)pix * p.ldx);
+            v1.load(x + (long long)(pix + PP) * p.ldx);
+            v2.load(x + (long long)(pix + 2 * PP) * p.ldx);
+            v3.load(x + (long long)(pix + 3 * PP) * p.ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f0 = v0.get(e), f1 = v1.get(e), f2 = v2.get(e), f3 = v3.get(e);
+                sum[e] += (f0 + f1) + (f2 + f3);
+                sq[e] = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, fmaf(f3, f3, sq[e]))));
+            }
+        }
+        for (; pix < p1; pix += PP) {
             Vec8<T> v;
             v.load(x + (long long)pix * p.ldx);
 #pragma unroll
@@ -64,12 +79,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
     float* gr = gm + p.groups;         // [groups]
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups;
+    // reduce the S partial sums of every group: 256/groups threads per group, then a fixed-order tree (deterministic)
+    float* ps = gr + p.groups;         // [nsl][groups][2]
+    const int nsl = 256 / p.groups;
+    {
+        const int g = tid % p.groups, sl = tid / p.groups;
+        float a = 0.f, q = 0.f;
+        if (sl < nsl)
+            for (int s = sl; s < p.S; s += nsl) {
+                const float* in = p.partial + (((long long)b * p.S + s) * p.groups + g) * 2;
+                a += in[0]; q += in[1];
+            }
+        if (sl < nsl) { ps[(sl * p.groups + g) * 2] = a; ps[(sl * p.groups + g) * 2 + 1] = q; }
+    }
+    __syncthreads();
     if (tid < p.groups) {
         float a = 0.f, q = 0.f;
-        for (int s = 0; s < p.S; ++s) {
-            const float* in = p.partial + (((long long)b * p.S + s) * p.groups + tid) * 2;
-            a += in[0]; q += in[1];
-        }
+        for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * p.groups + tid) * 2]; q += ps[(sl * p.groups + tid) * 2 + 1]; }
         const float n = (float)cpg * (float)p.HW;
         const float mean = a / n;
         float var = q / n - mean * mean;
@@ -98,7 +124,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
     const long long nitem = (long long)max(0, p1 - p0) * nchunk;
     const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx;
     T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy;
-    for (long long it = tid; it < nitem; it += 256) {
+    // 4 items per thread per trip: all loads are issued before the first use
+    long long it = tid;
+    for (; it + 3 * 256 < nitem; it += 4 * 256) {
+        Vec8<T> v[4];
+        int pixs[4], c0s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long q = it + u * 256;
+            pixs[u] = p0 + (int)(q / nchunk);
+            c0s[u] = (int)(q % nchunk) * 8;
+            v[u].load(x + (long long)pixs[u] * p.ldx + c0s[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.set(e, rs_apply_act(fmaf(v[u].get(e), ca[c0s[u] + e], cb[c0s[u] + e]), p.act));
+            o.store(y + (long long)pixs[u] * p.ldy + c0s[u]);
+        }
+    }
+    for (; it < nitem; it += 256) {
         const int pix = p0 + (int)(it / nchunk);
         const int c0 = (int)(it % nchunk) * 8;
         Vec8<T> v;
@@ -116,7 +162,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     const GNParams& p = *pp;
     if ((p.C % 8) || (p.C % p.groups) || p.C / 8 > 256 || p.groups > 256 || (p.ldx % 8) || (p.ldy % 8)) return -2;
     dim3 g1(p.S, p.B), g2(apply_slabs, p.B);
-    const size_t lds = (2 * p.C + 2 * p.groups) * sizeof(float);
+    const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
     if (dt == RS_F16) {
         hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
@@ -234,11 +280,148 @@ __global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
 
 }  // namespace
 
+namespace {
+
+// fp16 window attention on the matrix cores: one wave per (window, head), everything between the qkv tensor and the
+// output stays in registers except V, which is transposed through LDS.
+//   S^T = K Q^T   : 16 x v_mfma_f32_16x16x32_f16, A = K rows (16 B straight from global), B = Q rows (ditto);
+//                   lane (lr,lg) ends with S^T[j = 16fj+4lg+r][i = 16fi+lr]: all 64 keys of query i live in the 4
+//                   lanes lr, lr+16, lr+32, lr+48 -> the softmax row reduction is 2 xor-shuffles (16, 32).
+//   O^T = V^T P^T : 16 more MFMAs.  The B operand wants, per lane, 8 keys of ONE query: exactly the registers the lane
+//                   already holds (frags 2s and 2s+1), because the k-slot -> key map may be any bijection as long as
+//                   the A operand (V^T, read from LDS with two ds_read_b64) uses the same one.  No P round trip.
+//   The output lane holds 4 consecutive channels of one token -> 8-byte stores to the un-shifted, un-partitioned pixel.
+__global__ __launch_bounds__(512) void win_attn_mfma_kernel(WinAttnParams p) {
+    constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8;  // V^T row pitch in halfs (144 B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+    f16* vt = (f16*)smem + (size_t)h * HD * VP;  // [HD][VP] of this head
+    const int nwx = p.W / WS;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    const int b = blockIdx.y;
+    const int E = p.heads * HD;
+    const f16* qkv = (const f16*)p.qkv;
+    auto pixel = [&](int t) -> long long {
+        int sy = wy * WS + (t >> 3) + p.shift; if (sy >= p.H) sy -= p.H;
+        int sx = wx * WS + (t & 7) + p.shift; if (sx >= p.W) sx -= p.W;
+        return ((long long)b * p.H + sy) * p.W + sx;
+    };
+    // V^T staging: lane = token
+    {
+        const f16* vsrc = qkv + pixel(lane) * p.ldq + 2 * E + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const f16x8 v = *(const f16x8*)(vsrc + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vt[(8 * c + e) * VP + lane] = v[e];
+        }
+    }
+    long long pix[4];
+    f16x8 kf[4], qf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        pix[f] = pixel(16 * f + lr);
+        const f16* src = qkv + pix[f] * p.ldq + h * HD + 8 * lg;
+        qf[f] = *(const f16x8*)src;
+        kf[f] = *(const f16x8*)(src + E);
+    }
+    f32x4 s[4][4];  // [fj][fi]
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+            s[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[fj], qf[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    // region ids of the (quirky) shift mask: band of window_row*8 + token_column (see win_attn_kernel)
+    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+    if (p.shift > 0) {
+        auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
+        rid_i = band(lr & 7);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
+    }
+    float inv[4];
+    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+        const int i = 16 * fi + lr;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
+                s[fj][fi][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[fj][fi][r] - m);
+                s[fj][fi][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[fi] = 1.0f / l;
+    }
+    __syncthreads();  // V^T of every head is in LDS
+    f32x4 o[2][4];    // [fd][fi]
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 va[2], pb[4];
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            const f16* row = vt + (16 * fd + lr) * VP + 32 * ks + 4 * lg;
+            const f16x4 lo = *(const f16x4*)row, hi = *(const f16x4*)(row + 16);
+            va[fd] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const f32x4 a = s[2 * ks][fi], c = s[2 * ks + 1][fi];
+            pb[fi] = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+        }
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
+    }
+    f16* out = (f16*)p.out;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            f16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
+            *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+        }
+}
+
+}  // namespace
+
 extern "C" int rs_win_attn_launch(const WinAttnParams* pp, int dt, hipStream_t st) {
     const WinAttnParams& p = *pp;
     if ((p.H % 8) || (p.W % 8) || p.heads < 1 || p.heads > 8 || (p.ldq % 8) || (p.ldo % 8)) return -2;
     if (p.shift != 0 && p.shift != 4) return -2;
     dim3 grid((p.H / 8) * (p.W / 8), p.B), block(64 * p.heads);
+    if (dt == RS_F16 && p.bias_n) {
+        const size_t lds_m = (size_t)p.heads * 32 * (64 + 8) * sizeof(f16);
+        hipLaunchKernelGGL(win_attn_mfma_kernel, grid, block, lds_m, st, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const size_t lds = (size_t)2 * p.heads * 64 * 32 * sizeof(float) + 64 * sizeof(int);
     if (dt == RS_F16) {
         (void)hipFuncSetAttribute((const void*)win_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
