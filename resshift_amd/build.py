@@ -54,6 +54,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    # the library must resolve all of its own symbols (catches dropped kernel stubs); needs only libamdhip64, no GPU
+    chk = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
+    if chk.returncode != 0:
+        raise RuntimeError(f"built library does not load:\n{chk.stderr[-2000:]}")
     with open(stamp, "w") as fh:
         fh.write(dig)
     if verbose:

@@ -68,7 +68,7 @@ struct IGemmParams {
     long long bs_x0, bs_w, bs_y, bs_res;  // blockIdx.z batch strides in elements (batched GEMM mode)
     int splitk;          // >1: grid.z slices K; fp32 partial slabs in `partial`, finished by splitk_reduce_kernel
     float* partial;      // [splitk][M][Cout] fp32 workspace (caller owned)
-    const void* zeros;   // >= 16 zero bytes in global memory (filled in by the igemm2 launcher)
+    unsigned x_bytes, w_bytes;  // extents of the x0 / w buffers for the igemm2 buffer descriptors (filled in by its launcher)
 };
 
 struct DirectConvParams {

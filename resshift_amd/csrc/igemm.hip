@@ -371,9 +371,12 @@ extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
     const int bk = in_dt == RS_F16 ? 64 : 32;
     const int nk = (Ktot + bk - 1) / bk;
     if (tiles >= 200 || nk < 16 || (Cout & 3)) return 1;
-    int s = (512 + tiles - 1) / tiles;
-    s = std::min(s, 8);
-    s = std::min(s, nk / 8);
+    // aim at ~3 workgroups per CU, keep >= 6 K stages per slice (RS_SPLITK_TARGET / RS_SPLITK_MINSTAGES override for tuning)
+    static const int target = []() { const char* e = getenv("RS_SPLITK_TARGET"); return e ? atoi(e) : 512; }();
+    static const int minst = []() { const char* e = getenv("RS_SPLITK_MINSTAGES"); return e ? atoi(e) : 8; }();
+    int s = (target + tiles - 1) / tiles;
+    s = std::min(s, 16);
+    s = std::min(s, nk / minst);
     return std::max(s, 1);
 }
 
@@ -390,7 +393,7 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
     int bp2 = 0, bc2 = 0;
-    if (use_v2 && p.splitk == 1 && rs_igemm2_pick(p.M, p.Cout, nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
+    if (use_v2 && p.splitk == 1 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
     hipError_t e;
     if (in_dt == RS_F16 && out_dt == RS_F16) e = launch_t<f16, f16>(p, nz, st);
     else if (in_dt == RS_F16 && out_dt == RS_F32) e = launch_t<f16, float>(p, nz, st);

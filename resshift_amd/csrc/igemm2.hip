@@ -18,6 +18,54 @@ using namespace igemm_detail;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// One K stage of MFMAs with precomputed per-lane LDS base pointers: fragment i sits at base + i*2048 (16 rows x 128 B),
+// so every ds_read_b128 uses an immediate offset and the stage costs no address arithmetic beyond the 4 bases.
+template <typename T, int FC, int FP> struct Stage2;
+template <int FC, int FP> struct Stage2<f16, FC, FP> {
+    static __device__ __forceinline__ void run(const char* a0, const char* a1, const char* b0, const char* b1, f32x4 (&acc)[FC][FP]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* pa = ks ? a1 : a0;
+            const char* pb = ks ? b1 : b0;
+            f16x8 a[FC], b[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(pa + i * 2048);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) b[j] = *(const f16x8*)(pb + j * 2048);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+template <int FC, int FP> struct Stage2<float, FC, FP> {
+    static __device__ __forceinline__ void run(const char* a0, const char* a1, const char* b0, const char* b1, f32x4 (&acc)[FC][FP]) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const char* pa = ss ? a1 : a0;
+            const char* pb = ss ? b1 : b0;
+            f32x4 a[FC], b[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) a[i] = *(const f32x4*)(pa + i * 2048);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) b[j] = *(const f32x4*)(pb + j * 2048);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+// NB: keep the LDS-DMA builtin inside a plain __device__ function: called directly from the kernel template hipcc 7.2
+// silently drops the template's HOST stubs (undefined __device_stub__ symbols at load time).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename TI, typename TO, int BP, int BC, int NS>
@@ -30,7 +78,6 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     constexpr int FP = BP / 64;                // wave tile = (BP/4) pixels x (BC/2) channels
     constexpr int FC = BC / 32;
     constexpr int STAGE = (BP + BCP) * 128;
-    constexpr unsigned INVALID = 0xFFFFFFFFu;
     static_assert(BP % 64 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3), "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,12 +96,17 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     const int n0 = (tile % nby) * BC;
     const long long z = blockIdx.z;
 
+    // Operands are fetched with `buffer_load_dwordx4 ... lds`: a wave-uniform buffer descriptor per operand plus a 32-bit
+    // per-lane BYTE offset.  Out-of-image taps, rows beyond M / Cout and the K tail use an offset beyond num_records, for
+    // which the hardware returns zeros - no zero buffer, no pointer selects, and every wave still issues exactly L loads.
+    constexpr unsigned INV = 0xF0000000u;   // > any tensor size handled here (checked by the launcher)
+    constexpr unsigned SZ = sizeof(TI);
     const TI* x0 = (const TI*)p.x0 + z * p.bs_x0;
-    const TI* x1 = (const TI*)p.x1;
     const TI* w = (const TI*)p.w + z * p.bs_w;
-    const TI* zeros = (const TI*)p.zeros;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, p.w_bytes, 0x00020000);
 
-    const int Ctot = p.C0 + p.C1;
+    const int Ctot = p.C0;                  // single source only (the launcher routes channel-concat convs to igemm.hip)
     const int ntaps = p.KH * p.KW;
     const int Hv = p.Hs * p.up, Wv = p.Ws * p.up;
     const int ush = p.up == 2 ? 1 : 0;
@@ -76,20 +128,19 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
             pixbase[i] = -1; iy0[i] = 0; ix0[i] = 0;
         }
     }
-    // weight rows: 32-bit element offsets from w (INVALID -> zero row)
-    unsigned woff[RW];
+    unsigned woff[RW];                      // byte offset of this lane's weight rows
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int n = n0 + 64 * i + rr;
-        woff[i] = (64 * i + rr < BC && n < p.Cout) ? (unsigned)n * (unsigned)p.Ktot : INVALID;
+        woff[i] = (64 * i + rr < BC && n < p.Cout) ? (unsigned)n * (unsigned)p.Ktot * SZ : INV;
     }
     int kk = kcp * CH;
     int tap = kk / Ctot;
     int cc = kk - tap * Ctot;
 
-    // Address generation is incremental: the per-row pixel offsets (in elements, per source) only change when this
-    // lane's K cursor crosses into the next filter tap; between tap changes a stage costs one add per row.
-    unsigned off0[RX], off1[RX];
+    // Address generation is incremental: the per-row pixel byte offsets only change when this lane's K cursor crosses
+    // into the next filter tap; between tap changes a stage costs one add per row.
+    unsigned off[RX];
     auto set_tap = [&]() {
         const bool kvalid = tap < ntaps;
         const int ky = tap / p.KW;
@@ -99,8 +150,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool ok = kvalid && pixbase[i] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
             const unsigned pix = (unsigned)(pixbase[i] + (iy >> ush) * p.Ws + (ix >> ush));
-            off0[i] = ok ? pix * (unsigned)p.ld0 : INVALID;
-            off1[i] = ok ? pix * (unsigned)p.ld1 : INVALID;
+            off[i] = ok ? pix * (unsigned)p.ld0 * SZ : INV;
         }
     };
     set_tap();
@@ -108,21 +158,15 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     // issue the L LDS-DMA loads of one K stage into ring slot `slot`, then step this lane's K cursor
     auto issue = [&](int slot) {
         char* sbase = smem + slot * STAGE + (8 * wave) * 128;   // wave-uniform
-        const bool s0 = cc < p.C0;
-        const TI* base = s0 ? x0 + cc : x1 + (cc - p.C0);
+        const unsigned cb = (unsigned)cc * SZ;
 #pragma unroll
-        for (int i = 0; i < RX; ++i) {
-            const unsigned o = s0 ? off0[i] : off1[i];
-            const TI* g = (o != INVALID) ? base + o : zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sbase + (64 * i) * 128), 16, 0, 0);
-        }
-        const TI* wb = w + kk;
+        for (int i = 0; i < RX; ++i)
+            lds_dma16(rx, sbase + (64 * i) * 128, off[i] + cb);
         const bool wk = kk < p.Ktot;
+        const unsigned kb = (unsigned)kk * SZ;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const TI* g = (wk && woff[i] != INVALID) ? wb + woff[i] : zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sbase + (BP + 64 * i) * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < RW; ++i)
+            lds_dma16(rw, sbase + (BP + 64 * i) * 128, wk ? woff[i] + kb : INV);
         kk += BK;
         cc += BK;
         if (cc >= Ctot) {
@@ -130,6 +174,10 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
             set_tap();
         }
     };
+
+    // per-lane LDS fragment bases (relative to the ring slot): rows wrow0+lr / xrow0+lr, swizzled chunk for k-step 0/1
+    const int swz0 = ((lg ^ (lr & 7)) << 4), swz1 = (((4 + lg) ^ (lr & 7)) << 4);
+    const int la = BP * 128 + (wc * (BC / 2) + lr) * 128, lb = (wp * (BP / 4) + lr) * 128;
 
     f32x4 acc[FC][FP];
 #pragma unroll
@@ -148,7 +196,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
         // refill the slot every wave finished reading before this barrier
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS);
         const char* sb = smem + (kt % NS) * STAGE;
-        MfmaOps<TI>::template stage<FC, FP>(sb + BP * 128, sb, wc * (BC / 2), wp * (BP / 4), lr, lg, acc);
+        Stage2<TI, FC, FP>::run(sb + la + swz0, sb + la + swz1, sb + lb + swz0, sb + lb + swz1, acc);
     }
     __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
 
@@ -244,15 +292,6 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     }
 }
 
-const void* zero_buffer() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
-    }
-    return z;
-}
-
 template <typename TI, typename TO, int BP, int BC, int NS>
 hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     constexpr int BCP = (BC + 63) / 64 * 64;
@@ -264,8 +303,11 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)igemm2_kernel<TI, TO, BP, BC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    p.zeros = zero_buffer();
-    if (!p.zeros) return hipErrorOutOfMemory;
+    const size_t esz = sizeof(TI);
+    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * esz, wb = (size_t)p.Cout * p.Ktot * esz;
+    if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
     hipLaunchKernelGGL((igemm2_kernel<TI, TO, BP, BC, NS>), dim3(tiles, 1, nz), dim3(512), lds, st, p);
     return hipGetLastError();
 }
