@@ -132,10 +132,7 @@ def main():
     sharding.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.allreduce_max(elapsed, dev)
     assert torch.isfinite(out).all().item(), "non-finite output"
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed

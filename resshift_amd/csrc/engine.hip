@@ -517,9 +517,14 @@ struct rs_engine {
     }
     void gn(Exec& ex, const GNW& g, const View& x, const View& y, float eps, int act, const float* film = nullptr) {
         const int HW = x.H * x.W;
-        int S = std::max(1, std::min(64, 1024 / std::max(1, x.B)));
-        S = std::max(1, std::min(S, HW / 8));
-        int S2 = std::max(1, std::min(HW / 8, std::max(1, 2048 / std::max(1, x.B))));
+        // slab counts: enough workgroups to fill the chip, but every apply workgroup re-derives the per-channel
+        // coefficients, so slabs must stay fat enough to amortise that (RS_GN_BLOCKS_* override the targets for tuning)
+        static const int tgt1 = []() { const char* e = getenv("RS_GN_BLOCKS_STATS"); return e ? atoi(e) : 1024; }();
+        static const int tgt2 = []() { const char* e = getenv("RS_GN_BLOCKS_APPLY"); return e ? atoi(e) : 2048; }();
+        static const int minpx = []() { const char* e = getenv("RS_GN_MIN_PIXELS"); return e ? atoi(e) : 8; }();
+        int S = std::max(1, std::min(64, tgt1 / std::max(1, x.B)));
+        S = std::max(1, std::min(S, HW / minpx));
+        int S2 = std::max(1, std::min(HW / minpx, std::max(1, tgt2 / std::max(1, x.B))));
         float* partial = (float*)ex.raw((size_t)x.B * S * 32 * 2 * sizeof(float));
         if (ex.dry) return;
         GNParams p{};

@@ -27,8 +27,9 @@ def init_distributed() -> Tuple[int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", init_method="env://", rank=rank,
-                                world_size=world)
+        # RCCL ("nccl") on GPUs; RESSHIFT_DIST_BACKEND=gloo lets several ranks share one GPU for plumbing tests
+        backend = os.environ.get("RESSHIFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return world, rank
 
 
@@ -58,8 +59,22 @@ def shard_noise(noise: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     """One collective for the whole packed weight blob (flat uint8 tensor)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(blob, src=src)
+        if blob.is_cuda and dist.get_backend() == "gloo":  # test-only path: stage through the host
+            host = blob.cpu()
+            dist.broadcast(host, src=src)
+            blob.copy_(host)
+        else:
+            dist.broadcast(blob, src=src)
     return blob
+
+
+def allreduce_max(value: float, device) -> float:
+    """max over ranks of a python float (bench timing)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def gather_images(local: torch.Tensor, n_global: int, rank: int, world: int) -> torch.Tensor:

@@ -81,6 +81,46 @@ def test_conv_igemm(gpu, dtype, case):
     _close(y.permute(0, 3, 1, 2), ref, TOL[dtype], f"conv {case} {dtype}")
 
 
+BIG_CONV_CASES = [
+    # shapes large enough for the second-generation LDS-DMA kernel (igemm2.hip): B, H, W, Cin, Cout, k, up, act, res
+    (8, 64, 64, 160, 160, 3, 1, 0, True),     # 128-pixel tiles, BC=160, 3-stage ring
+    (16, 64, 64, 160, 160, 3, 1, 0, True),    # 256-pixel tiles, BC=160, 2-stage ring
+    (16, 64, 64, 192, 576, 1, 1, 0, False),   # qkv: BC=192, K = 192 (3 stages, ring tail handling)
+    (16, 64, 64, 192, 768, 1, 1, 1, False),   # fc1 + GELU
+    (16, 32, 32, 320, 320, 3, 2, 0, False),   # nearest-x2 upsample folded, 256-pixel tiles
+    (4, 128, 128, 128, 128, 3, 1, 0, True),   # AE level: BC=128, 3-stage ring, 256-pixel tiles
+    (9, 60, 52, 160, 320, 3, 1, 0, False),    # ragged M (not a multiple of the tile), two channel tiles
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("case", BIG_CONV_CASES)
+def test_conv_igemm2_large(gpu, dtype, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, k, up, act, use_res = case
+    if dtype == torch.float32 and B > 8:
+        B = 8 if case[1] * case[2] >= 4096 else B  # keep the fp32 CPU reference quick; still >= 200 tiles
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xd = _nhwc(x, dtype, gpu)
+    xr = _ref_in(xd)
+    if up == 2:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xr, w.to(dtype).float(), b, padding=k // 2)
+    if act == 1:
+        ref = F.gelu(ref)
+    res_d = None
+    if use_res:
+        res_d = _nhwc(torch.randn(ref.shape, generator=g), dtype, gpu)
+        ref = ref + _ref_in(res_d)
+    y = ops.conv2d(xd, w, b, res=res_d, pad=(k // 2, k // 2), up=up, act=act)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, TOL[dtype], f"big conv {case} {dtype}")
+
+
 def test_conv_identity_asymmetric(gpu):
     """A = I check with an asymmetric operand: catches a transposed MFMA output mapping."""
     from resshift_amd import ops
