@@ -359,14 +359,24 @@ hipError_t launch_t(const IGemmParams& p, int nz, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int rs_igemm2_pick(int M, int Cout, int nz, int* BP, int* BC);
+extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int* BC);
 extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, int BP, int BC, int nz, hipStream_t st);
+
+extern "C" int rs_splitk_reduce_launch(const IGemmParams* pp, int out_dt, hipStream_t st) {
+    const IGemmParams& p = *pp;
+    const long long nq = (long long)p.M * (p.Cout >> 2);
+    const unsigned blocks = (unsigned)std::min<long long>((nq + 255) / 256, 4096);
+    if (out_dt == RS_F16) hipLaunchKernelGGL((splitk_reduce_kernel<f16>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // Split-K planner: returns the number of K slices (1 = no split) for a single (non-batched) launch.  The caller owns the
 // fp32 workspace of splitk * M * Cout floats (IGemmParams::partial).
 extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
     int BP, BC;
     pick_tile(M, Cout, BP, BC);
+    if (Cout > 64) BP = 128;  // igemm2 (128-pixel tiles) takes every single-source launch with more than 64 channels
     const int tiles = ((M + BP - 1) / BP) * ((Cout + BC - 1) / BC);
     const int bk = in_dt == RS_F16 ? 64 : 32;
     const int nk = (Ktot + bk - 1) / bk;
@@ -393,7 +403,7 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
     int bp2 = 0, bc2 = 0;
-    if (use_v2 && p.splitk == 1 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
+    if (use_v2 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, p.Ktot * (in_dt == RS_F16 ? 2 : 4), nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
     hipError_t e;
     if (in_dt == RS_F16 && out_dt == RS_F16) e = launch_t<f16, f16>(p, nz, st);
     else if (in_dt == RS_F16 && out_dt == RS_F32) e = launch_t<f16, float>(p, nz, st);

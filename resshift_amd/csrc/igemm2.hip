@@ -11,6 +11,8 @@
 #include "igemm_common.h"
 #include <algorithm>
 
+extern "C" int rs_splitk_reduce_launch(const IGemmParams* p, int out_dt, hipStream_t st);
+
 namespace {
 
 using namespace igemm_detail;
@@ -68,17 +70,19 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename TI, typename TO, int BP, int BC, int NS>
-__global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
+template <typename TI, typename TO, int BP, int BC, int NS, int NWV>
+__global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
+    constexpr int WPN = NWV / 2;               // pixel-waves (x 2 channel-waves)
+    constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
     constexpr int CH = MfmaOps<TI>::CH;
     constexpr int BK = 8 * CH;                 // elements of K per stage (128 bytes per row)
-    constexpr int BCP = (BC + 63) / 64 * 64;   // weight rows rounded to whole 64-row load rounds
-    constexpr int RX = BP / 64, RW = BCP / 64; // load rounds (one global_load_lds per thread per round)
+    constexpr int BCP = (BC + RND - 1) / RND * RND;   // weight rows rounded to whole load rounds
+    constexpr int RX = BP / RND, RW = BCP / RND;      // load rounds (one LDS-DMA instruction per thread per round)
     constexpr int L = RX + RW;                 // LDS-DMA instructions per thread per stage
-    constexpr int FP = BP / 64;                // wave tile = (BP/4) pixels x (BC/2) channels
+    constexpr int FP = BP / WPN / 16;          // wave tile = (BP/WPN) pixels x (BC/2) channels
     constexpr int FC = BC / 32;
     constexpr int STAGE = (BP + BCP) * 128;
-    static_assert(BP % 64 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3), "tile");
+    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3) && (NWV == 4 || NWV == 8), "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const int wp = wave & 3, wc = wave >> 2;
+    const int wp = wave % WPN, wc = wave / WPN;
     const int rr = 8 * wave + (lane >> 3);             // row inside a 64-row load round
     const int kcp = (lane & 7) ^ ((lane >> 3) & 7);    // source K-chunk of this lane (swizzle on the source side)
 
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     // which the hardware returns zeros - no zero buffer, no pointer selects, and every wave still issues exactly L loads.
     constexpr unsigned INV = 0xF0000000u;   // > any tensor size handled here (checked by the launcher)
     constexpr unsigned SZ = sizeof(TI);
-    const TI* x0 = (const TI*)p.x0 + z * p.bs_x0;
-    const TI* w = (const TI*)p.w + z * p.bs_w;
+    const TI* x0 = (const TI*)p.x0 + (p.splitk > 1 ? 0 : z * p.bs_x0);
+    const TI* w = (const TI*)p.w + (p.splitk > 1 ? 0 : z * p.bs_w);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, p.w_bytes, 0x00020000);
 
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     int pixbase[RX], iy0[RX], ix0[RX];
 #pragma unroll
     for (int i = 0; i < RX; ++i) {
-        const int m = m0 + 64 * i + rr;
+        const int m = m0 + RND * i + rr;
         if (m < p.M) {
             const int b = m / HoWo;
             const int rem = m - b * HoWo;
@@ -131,10 +135,19 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     unsigned woff[RW];                      // byte offset of this lane's weight rows
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        const int n = n0 + 64 * i + rr;
-        woff[i] = (64 * i + rr < BC && n < p.Cout) ? (unsigned)n * (unsigned)p.Ktot * SZ : INV;
+        const int n = n0 + RND * i + rr;
+        woff[i] = (RND * i + rr < BC && n < p.Cout) ? (unsigned)n * (unsigned)p.Ktot * SZ : INV;
     }
-    int kk = kcp * CH;
+    // K range of this workgroup (split-K: grid.z slices the K stages; batch strides are unused then)
+    const bool split = p.splitk > 1;
+    const int nk_total = (p.Ktot + BK - 1) / BK;
+    int kt0 = 0, nk = nk_total;
+    if (split) {
+        const int per = (nk_total + p.splitk - 1) / p.splitk;
+        kt0 = min(nk_total, (int)z * per);
+        nk = min(nk_total, kt0 + per) - kt0;
+    }
+    int kk = kt0 * BK + kcp * CH;
     int tap = kk / Ctot;
     int cc = kk - tap * Ctot;
 
@@ -161,12 +174,12 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
         const unsigned cb = (unsigned)cc * SZ;
 #pragma unroll
         for (int i = 0; i < RX; ++i)
-            lds_dma16(rx, sbase + (64 * i) * 128, off[i] + cb);
+            lds_dma16(rx, sbase + (RND * i) * 128, off[i] + cb);
         const bool wk = kk < p.Ktot;
         const unsigned kb = (unsigned)kk * SZ;
 #pragma unroll
         for (int i = 0; i < RW; ++i)
-            lds_dma16(rw, sbase + (BP + 64 * i) * 128, wk ? woff[i] + kb : INV);
+            lds_dma16(rw, sbase + (BP + RND * i) * 128, wk ? woff[i] + kb : INV);
         kk += BK;
         cc += BK;
         if (cc >= Ctot) {
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
 
     // per-lane LDS fragment bases (relative to the ring slot): rows wrow0+lr / xrow0+lr, swizzled chunk for k-step 0/1
     const int swz0 = ((lg ^ (lr & 7)) << 4), swz1 = (((4 + lg) ^ (lr & 7)) << 4);
-    const int la = BP * 128 + (wc * (BC / 2) + lr) * 128, lb = (wp * (BP / 4) + lr) * 128;
+    const int la = BP * 128 + (wc * (BC / 2) + lr) * 128, lb = (wp * (BP / WPN) + lr) * 128;
 
     f32x4 acc[FC][FP];
 #pragma unroll
@@ -185,9 +198,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.Ktot + BK - 1) / BK;
     // prologue: fill NS-1 ring slots
-    issue(0);
+    if (nk > 0) issue(0);
     if (NS == 3 && nk > 1) issue(1);
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt has landed once at most the loads of the NS-2 later stages are still outstanding
@@ -201,15 +213,33 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
 
     // ---------------------------------------------------------------- epilogue (as in igemm.hip)
+    if (split) {
+        // raw fp32 partial sums; scale / bias / activation / residual are applied by the split-K reduce kernel
+        float* part = p.partial + z * (long long)p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (n >= p.Cout) continue;
+                float* pp = part + (long long)m * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) *(f32x4*)pp = acc[i][j];
+                else for (int r = 0; r < 4 && n + r < p.Cout; ++r) pp[r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
     TO* y = (TO*)p.y + z * p.bs_y;
     const TO* res = p.res ? (const TO*)p.res + z * p.bs_res : nullptr;
     const bool res_vec = res && (p.ldres & 3) == 0;
     if constexpr (sizeof(TO) == 2) {
         constexpr int ROWB = (BC / 2) * 2 + 16;
-        char* stg = smem + wave * (BP / 4) * ROWB;
+        char* stg = smem + wave * (BP / WPN) * ROWB;
 #pragma unroll
         for (int j = 0; j < FP; ++j) {
-            const int m = m0 + wp * (BP / 4) + j * 16 + lr;
+            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 const int nl = i * 16 + lg * 4;
@@ -238,11 +268,11 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
         }
         __syncthreads();
         constexpr int CPR = (BC / 2) / 8;
-        constexpr int NITEM = (BP / 4) * CPR;
+        constexpr int NITEM = (BP / WPN) * CPR;
         const bool vec_ok = (p.ldy & 7) == 0;
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;
-            const int m = m0 + wp * (BP / 4) + row;
+            const int m = m0 + wp * (BP / WPN) + row;
             const int n = n0 + wc * (BC / 2) + c8 * 8;
             if (m >= p.M || n >= p.Cout) continue;
             const uint4 v = *(const uint4*)(stg + row * ROWB + c8 * 16);
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
         const bool vec_ok = ((p.ldy & 3) == 0);
 #pragma unroll
         for (int j = 0; j < FP; ++j) {
-            const int m = m0 + wp * (BP / 4) + j * 16 + lr;
+            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
             if (m >= p.M) continue;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
@@ -292,15 +322,16 @@ __global__ __launch_bounds__(512) void igemm2_kernel(IGemmParams p) {
     }
 }
 
-template <typename TI, typename TO, int BP, int BC, int NS>
+template <typename TI, typename TO, int BP, int BC, int NS, int NWV = 8>
 hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
-    constexpr int BCP = (BC + 63) / 64 * 64;
+    constexpr int RND = 8 * NWV;
+    constexpr int BCP = (BC + RND - 1) / RND * RND;
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)NS * (BP + BCP) * 128;
     static_assert(NS * (BP + BCP) * 128 <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm2_kernel<TI, TO, BP, BC, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm2_kernel<TI, TO, BP, BC, NS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const size_t esz = sizeof(TI);
@@ -308,7 +339,8 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
-    hipLaunchKernelGGL((igemm2_kernel<TI, TO, BP, BC, NS>), dim3(tiles, 1, nz), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((igemm2_kernel<TI, TO, BP, BC, NS, NWV>), dim3(tiles, 1, p.splitk > 1 ? p.splitk : nz), dim3(64 * NWV), lds, st, p);
+    if (p.splitk > 1 && rs_splitk_reduce_launch(&p, sizeof(TO) == 2 ? RS_F16 : RS_F32, st) != 0) return hipErrorLaunchFailure;
     return hipGetLastError();
 }
 
@@ -319,6 +351,23 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
             case 160: return launch2_cfg<TI, TO, 256, 160, 2>(p, nz, st);
             case 192: return launch2_cfg<TI, TO, 256, 192, 2>(p, nz, st);
             default: return launch2_cfg<TI, TO, 256, 128, 3>(p, nz, st);
+        }
+    }
+    if (BP == 130) {
+        // 4-wave variant: wave tile 64 x BC/2 (fewer LDS fragment reads per MFMA), two workgroups per CU
+        switch (BC) {
+            case 160: return launch2_cfg<TI, TO, 128, 160, 2, 4>(p, nz, st);
+            case 192: return launch2_cfg<TI, TO, 128, 192, 2, 4>(p, nz, st);
+            default: return launch2_cfg<TI, TO, 128, 128, 2, 4>(p, nz, st);
+        }
+    }
+    if (BP == 129) {
+        // short-K GEMMs (K <= 4 stages: Swin qkv/proj/fc1, patch embeds): the launch is dominated by prologue + epilogue,
+        // so use the 2-stage ring (<= 80 KB of LDS) that lets TWO workgroups share a CU and overlap each other
+        switch (BC) {
+            case 160: return launch2_cfg<TI, TO, 128, 160, 2>(p, nz, st);
+            case 192: return launch2_cfg<TI, TO, 128, 192, 2>(p, nz, st);
+            default: return launch2_cfg<TI, TO, 128, 128, 2>(p, nz, st);
         }
     }
     switch (BC) {
@@ -332,7 +381,7 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
 
 // Tile choice of the second-generation kernel; returns 0 when the launch should stay on igemm.hip (tiny Cout,
 // too few tiles to fill the chip -> split-K there).
-extern "C" int rs_igemm2_pick(int M, int Cout, int nz, int* BP, int* BC) {
+extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int* BC) {
     if (Cout <= 64) return 0;
     auto waste = [&](int bc) { return ((Cout + bc - 1) / bc) * bc - Cout; };
     int best = 128, bw = waste(128);
@@ -340,8 +389,14 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int nz, int* BP, int* BC) {
     if (waste(192) < bw) { best = 192; bw = waste(192); }
     *BC = best;
     const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + best - 1) / best) * nz;
-    if (tiles128 < 200) return 0;
+    (void)tiles128;
     *BP = (tiles128 >= 512) ? 256 : 128;   // 256-pixel tiles once they still give >= 1 workgroup per CU
+    // measured (profiles/r1_igemm_microbench_*): the 128-pixel, 2-stage, two-workgroups-per-CU variant wins on every layer
+    // shape of the model; RS_IGEMM_SHORTK=<bytes> restricts it to short-K GEMMs (256-pixel tiles otherwise) for A/B runs
+    static const int shortk = []() { const char* e = getenv("RS_IGEMM_SHORTK"); return e ? atoi(e) : (1 << 30); }();
+    if (Kbytes <= shortk) *BP = 129;
+    static const int var4 = []() { const char* e = getenv("RS_IGEMM_4WAVE"); return e ? atoi(e) : 0; }();
+    if (var4) *BP = 130;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;
 }
 
