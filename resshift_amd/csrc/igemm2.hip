@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     constexpr int FP = BP / WPN / 16;          // wave tile = (BP/WPN) pixels x (BC/2) channels
     constexpr int FC = BC / 32;
     constexpr int STAGE = (BP + BCP) * 128;
-    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3) && (NWV == 4 || NWV == 8), "tile");
+    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3) && (NWV == 4 || NWV == 8 || NWV == 16), "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -353,6 +353,14 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
             default: return launch2_cfg<TI, TO, 256, 128, 3>(p, nz, st);
         }
     }
+    if (BP == 131) {
+        // 16-wave variant: 256-pixel tile (25 % less L2->LDS traffic per FLOP than 128x128) with the same 32 x BC/2 wave tiles
+        switch (BC) {
+            case 160: return launch2_cfg<TI, TO, 256, 160, 2, 16>(p, nz, st);
+            case 192: return launch2_cfg<TI, TO, 256, 192, 2, 16>(p, nz, st);
+            default: return launch2_cfg<TI, TO, 256, 128, 2, 16>(p, nz, st);
+        }
+    }
     if (BP == 130) {
         // 4-wave variant: wave tile 64 x BC/2 (fewer LDS fragment reads per MFMA), two workgroups per CU
         switch (BC) {
@@ -396,7 +404,8 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
     static const int shortk = []() { const char* e = getenv("RS_IGEMM_SHORTK"); return e ? atoi(e) : (1 << 30); }();
     if (Kbytes <= shortk) *BP = 129;
     static const int var4 = []() { const char* e = getenv("RS_IGEMM_4WAVE"); return e ? atoi(e) : 0; }();
-    if (var4) *BP = 130;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
+    if (var4 == 1) *BP = 130;
+    if (var4 == 16 && tiles128 >= 1024) *BP = 131;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;
 }
 

@@ -159,3 +159,42 @@ def test_sampler_drop_in_sample_func(gpu):
     torch.cuda.synchronize()
     assert tuple(out.shape) == (2, 3, 52, 40) and out.abs().max().item() <= 1.0
     assert H.psnr(out.cpu(), ref) >= 60.0
+
+
+@pytest.mark.parametrize("cname,hw,with_mask", [("realsr_swinunet_realesrgan256_journal", 64, False),
+                                                ("faceir_gfpgan512_lpips", 512, False),
+                                                ("inpaint_lama256_imagenet", 256, True)])
+def test_other_baseline_configs_full_size_vs_oracle(gpu, cname, hw, with_mask):
+    """BASELINE.json configs[2..4] at full size, B=1, exact kernels vs the CPU oracle on the same seeded weights / inputs /
+    noise: 4-step journal SR, 512x512 face restoration (f8 autoencoder, 3-stage feature extractor, 8-channel latent) and
+    256x256 inpainting (mask concatenated to the conditioning)."""
+    from resshift_amd import create_gaussian_diffusion
+
+    cfg = H.to_plain(H.load_config(cname))
+    up, ap, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    f = 2 ** (len(ap["ddconfig"]["ch_mult"]) - 1)
+    hz = hw * dp["sf"] // f
+    y, noises, mask = H.synth.synthetic_inputs(H.SEED_X, 1, hw, hw, ap["embed_dim"], hz, hz, dp["steps"], with_mask=with_mask)
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    d = create_gaussian_diffusion(**dp)
+    d.set_precision("fp32", "fp32", "fp32")
+    kw = {"lq": y.to(gpu)}
+    if with_mask:
+        kw["mask"] = mask.to(gpu)
+    out, gaux = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                                step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    agree = (gaux["indices"].cpu().long() == aux["indices"]).float().mean().item()
+    p = H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1))
+    print(f"{cname} fp32: image PSNR {p:.1f} dB, VQ agreement {agree:.4f}, latent rel err {H.rel_err(gaux['z_final'], aux['z_final']):.2e}")
+    assert agree >= 0.995 and p >= 60.0
+    d.set_precision("fp16", "fp16", "fp16")
+    out16, g16 = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                                 step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    zr = aux["z_final"]
+    lat = H.psnr(g16["z_final"].cpu(), zr, peak_to_peak=(zr.max() - zr.min()).item())
+    print(f"{cname} fp16: latent PSNR {lat:.1f} dB, image PSNR {H.psnr(out16.cpu().clamp(-1, 1), ref.clamp(-1, 1)):.1f} dB")
+    assert lat >= 40.0
