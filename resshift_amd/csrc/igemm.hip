@@ -403,7 +403,7 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
     int bp2 = 0, bc2 = 0;
-    if (use_v2 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, p.Ktot * (in_dt == RS_F16 ? 2 : 4), nz, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
+    if (use_v2 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, p.Ktot * (in_dt == RS_F16 ? 2 : 4), nz * p.splitk, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
     hipError_t e;
     if (in_dt == RS_F16 && out_dt == RS_F16) e = launch_t<f16, f16>(p, nz, st);
     else if (in_dt == RS_F16 && out_dt == RS_F32) e = launch_t<f16, float>(p, nz, st);

@@ -20,6 +20,10 @@ using namespace igemm_detail;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// s_setprio(1) around the MFMA clusters measured neutral here (4 waves/SIMD already interleave); kept as a build-time knob
+#ifndef RS_SETPRIO
+#define RS_SETPRIO 0
+#endif
 // One K stage of MFMAs with precomputed per-lane LDS base pointers: fragment i sits at base + i*2048 (16 rows x 128 B),
 // so every ds_read_b128 uses an immediate offset and the stage costs no address arithmetic beyond the 4 bases.
 template <typename T, int FC, int FP> struct Stage2;
@@ -34,10 +38,12 @@ template <int FC, int FP> struct Stage2<f16, FC, FP> {
             for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(pa + i * 2048);
 #pragma unroll
             for (int j = 0; j < FP; ++j) b[j] = *(const f16x8*)(pb + j * 2048);
+            if (RS_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
                 for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (RS_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
 };
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     constexpr int FP = BP / WPN / 16;          // wave tile = (BP/WPN) pixels x (BC/2) channels
     constexpr int FC = BC / 32;
     constexpr int STAGE = (BP + BCP) * 128;
-    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && (NS == 2 || NS == 3) && (NWV == 4 || NWV == 8 || NWV == 16), "tile");
+    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && (NS >= 2 && NS <= 4) && (NWV == 4 || NWV == 8 || NWV == 16), "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -200,10 +206,14 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
 
     // prologue: fill NS-1 ring slots
     if (nk > 0) issue(0);
-    if (NS == 3 && nk > 1) issue(1);
+    if (NS >= 3 && nk > 1) issue(1);
+    if (NS >= 4 && nk > 2) issue(2);
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt has landed once at most the loads of the NS-2 later stages are still outstanding
-        if (NS == 3 && kt + 1 < nk) wait_vmcnt<L>(); else wait_vmcnt<0>();
+        {
+            const int later = min(NS - 2, nk - 1 - kt);   // stages issued after kt that may still be in flight
+            if (later >= 2) wait_vmcnt<2 * L>(); else if (later == 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         // refill the slot every wave finished reading before this barrier
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS);
@@ -353,6 +363,14 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
             default: return launch2_cfg<TI, TO, 256, 128, 3>(p, nz, st);
         }
     }
+    if (BP == 132) {
+        // launches with fewer workgroups than CUs (16x16 / 8x8 UNet levels): latency-bound K loop -> deepest ring that fits
+        switch (BC) {
+            case 160: return launch2_cfg<TI, TO, 128, 160, 3>(p, nz, st);
+            case 192: return launch2_cfg<TI, TO, 128, 192, 3>(p, nz, st);
+            default: return launch2_cfg<TI, TO, 128, 128, 4>(p, nz, st);
+        }
+    }
     if (BP == 131) {
         // 16-wave variant: 256-pixel tile (25 % less L2->LDS traffic per FLOP than 128x128) with the same 32 x BC/2 wave tiles
         switch (BC) {
@@ -404,6 +422,8 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
     static const int shortk = []() { const char* e = getenv("RS_IGEMM_SHORTK"); return e ? atoi(e) : (1 << 30); }();
     if (Kbytes <= shortk) *BP = 129;
     static const int var4 = []() { const char* e = getenv("RS_IGEMM_4WAVE"); return e ? atoi(e) : 0; }();
+    static const int deep = []() { const char* e = getenv("RS_IGEMM_DEEP"); return e ? atoi(e) : 0; }();  // measured: no gain on the 8x8/16x16 levels (fixed launch cost dominates)
+    if (tiles128 <= deep) *BP = 132;
     if (var4 == 1) *BP = 130;
     if (var4 == 16 && tiles128 >= 1024) *BP = 131;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;

@@ -127,15 +127,11 @@ class ResShiftDiffusion:
     # ---- reference API
     @staticmethod
     def _axpbypcz(x, z, n, a, b, c, engine=None):
-        """a*x + b*z + c*n on the engine's elementwise kernel (torch arithmetic only for foreign callers without one)."""
-        if engine is not None and x.is_cuda:
-            return engine.axpbypcz(x, z, n, a, b, c).to(x.dtype)
-        out = a * x
-        if z is not None:
-            out = out + b * z
-        if n is not None:
-            out = out + c * n
-        return out
+        """a*x + b*z + c*n on the engine's elementwise kernel.  There is deliberately no torch/CPU arithmetic path: the
+        step-wise API needs the engine-backed UNetModelSwin (it owns the device kernels)."""
+        if engine is None or not x.is_cuda:
+            raise RuntimeError("step-wise sampling needs the HIP engine (engine-backed UNetModelSwin on a GPU); no CPU fallback")
+        return engine.axpbypcz(x, z, n, a, b, c).to(x.dtype)
 
     def _scale_input(self, inputs, t, engine=None):
         tab = self.step_tables()["inv_std"]
@@ -181,11 +177,10 @@ class ResShiftDiffusion:
         ti = int(t[0])
         prec = self._unet_precisions()[ti]
         ts = [self.timestep_map[ti]] * x_t.shape[0]  # _WrappedModel (respace.py:67-70)
-        eng = model.engine() if isinstance(model, UNetModelSwin) else None
-        if eng is not None:
-            pred = model(self._scale_input(x_t, ti, eng), ts, prec=prec, **model_kwargs)
-        else:
-            pred = model(self._scale_input(x_t, ti), torch.tensor(ts, device=x_t.device), **model_kwargs)
+        if not isinstance(model, UNetModelSwin):
+            raise NotImplementedError("p_mean_variance drives the engine-backed UNetModelSwin only")
+        eng = model.engine()
+        pred = model(self._scale_input(x_t, ti, eng), ts, prec=prec, **model_kwargs)
         if denoised_fn is not None:
             pred = denoised_fn(pred)
         if clip_denoised:
