@@ -153,9 +153,20 @@ def main():
         tot = f16 + f32
         peak_eff = tot / (f16 / MFMA_PEAK_TFLOPS["fp16"] + f32 / MFMA_PEAK_TFLOPS["fp32"]) if tot else MFMA_PEAK_TFLOPS["fp16"]
         achieved = tot / (st["igemm_ms"] * 1e-3) / 1e12 if st["igemm_ms"] > 0 else 0.0
+        # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
+        # passes of this very command, corrected as MI355X_MICROARCH.md prescribes) - collected offline by
+        # scripts/collect_traffic.py into profiles/, because a process cannot attach rocprofv3 to itself
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic_igemm.json")
+        if args.precision == "fp16" and B == 32 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)["hbm_bytes_per_launch"] / 1e6, 2)  # MB per launch
         roofline = {
-            "bound": "mfma", "kernel": "igemm_kernel<*> (implicit-GEMM conv/linear/bmm)", "achieved": round(achieved, 2),
-            "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None, "traffic": None,
+            "bound": "mfma", "kernel": "igemm2_kernel<*> / igemm_kernel<*> (implicit-GEMM conv/linear/bmm)", "achieved": round(achieved, 2),
+            "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
+            "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)",
+            "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),
+            "algorithmic_gflop_per_launch": round(tot / max(1, st["igemm_launches"]) / 1e9, 2),
             "launches_per_step": st["igemm_launches"], "avg_launch_us": round(st["igemm_ms"] * 1e3 / max(1, st["igemm_launches"]), 2),
             "algorithmic_gflop_per_image_igemm": round(tot / B / 1e9, 1), "algorithmic_gflop_per_image_total": GFLOP_PER_IMAGE,
             "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(GFLOP_PER_IMAGE * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),

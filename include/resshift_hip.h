@@ -122,16 +122,23 @@ int rs_sample(rs_engine* e, const rs_sample_args* a);
 /* fp32 y = a*x + b*z + c*n on device (posterior mean / prior sample for the step-wise API) */
 int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long count, void* stream);
 
+/* overlap-average tiling of large images (utils/util_image.py:889-979 ImageSpliterTh.update / .gather): NCHW fp32,
+ * acc[b,c,h0:h0+th,w0:w0+tw] += tile, count[h0:h0+th,w0:w0+tw] += 1; finalize divides acc by count in place */
+int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C, int H, int W, int h0, int w0, int th, int tw,
+                       void* stream);
+int rs_tile_finalize(float* acc, const float* count, int B, int C, int H, int W, void* stream);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 /* bytes of scratch arena currently allocated; number of kernel launches issued by the last call */
 size_t rs_arena_bytes(rs_engine* e);
 long long rs_last_launch_count(rs_engine* e);
 /* profiling of the MFMA implicit-GEMM kernel family: when enabled every igemm launch of the next call is
- * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[4] = {fp16-input igemm FLOPs,
- * fp32-input igemm FLOPs, summed igemm kernel milliseconds, igemm launch count} of the last call
- * (FLOP counts are always maintained; the time is 0 unless profiling was on). */
+ * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[5] = {fp16-input igemm FLOPs,
+ * fp32-input igemm FLOPs, summed igemm kernel milliseconds, igemm launch count, algorithmic HBM bytes (every
+ * operand and result counted once)} of the last call (counts are always maintained; the time is 0 unless
+ * profiling was on). */
 int rs_profile_enable(rs_engine* e, int on);
-int rs_profile_get(rs_engine* e, double* out4);
+int rs_profile_get(rs_engine* e, double* out5);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
 int rs_debug_enable(rs_engine* e, int on);

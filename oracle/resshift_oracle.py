@@ -366,3 +366,43 @@ def sample_func(unet_sd, unet_p, ae_sd, ae_p, dp, y0, noises, mask=None, padding
     if ph or pw:
         out = out[:, :, : H * sf, : W * sf]
     return out.clamp_(-1.0, 1.0)
+
+
+# ----------------------------------------------------------------------------- tiled large-image path
+def tile_starts(length: int, pch_size: int, stride: int) -> List[int]:
+    """utils/util_image.py:922-931 (ImageSpliterTh.extract_starts)."""
+    if length <= pch_size:
+        return [0]
+    starts = list(range(0, length, stride))
+    for ii in range(len(starts)):
+        if starts[ii] + pch_size > length:
+            starts[ii] = length - pch_size
+    return sorted(set(starts), key=starts.index)
+
+
+def sample_tiled(unet_sd, unet_p, ae_sd, ae_p, dp, im_lq, tile_noises, mask=None, chop_size=64, chop_stride=48, chop_bs=1,
+                 padding_offset=64):
+    """sampler.py:176-216 + utils/util_image.py:889-979: overlapping tiles, `chop_bs` tiles per sample_func call,
+    sum / count averaging.  tile_noises[k] = list of noise tensors for the k-th sample_func call."""
+    sf = int(dp.get("sf", 4))
+    B, _, H, W = im_lq.shape
+    if not (H > chop_size or W > chop_size):
+        return sample_func(unet_sd, unet_p, ae_sd, ae_p, dp, im_lq, tile_noises[0], mask=mask, padding_offset=padding_offset)
+    x = torch.cat([im_lq, mask], dim=1) if mask is not None else im_lq
+    starts = [(i, j) for i in tile_starts(H, chop_size, chop_stride) for j in tile_starts(W, chop_size, chop_stride)]
+    res = count = None
+    for k, c0 in enumerate(range(0, len(starts), chop_bs)):
+        cur = starts[c0:c0 + chop_bs]
+        pch = torch.cat([x[:, :, h0:h0 + chop_size, w0:w0 + chop_size] for h0, w0 in cur], dim=0)
+        m = None
+        if mask is not None:
+            pch, m = pch[:, :-1], pch[:, -1:]
+        out = sample_func(unet_sd, unet_p, ae_sd, ae_p, dp, pch, tile_noises[k], mask=m, padding_offset=padding_offset)
+        if res is None:
+            res = torch.zeros(B, out.shape[1], H * sf, W * sf)
+            count = torch.zeros_like(res)
+        for t, (h0, w0) in enumerate(cur):
+            res[:, :, h0 * sf:(h0 + chop_size) * sf, w0 * sf:(w0 + chop_size) * sf] += out[t * B:(t + 1) * B]
+            count[:, :, h0 * sf:(h0 + chop_size) * sf, w0 * sf:(w0 + chop_size) * sf] += 1
+    assert torch.all(count != 0)
+    return res / count

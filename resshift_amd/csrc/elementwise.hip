@@ -155,6 +155,26 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* z, const f
     if (idx_out) idx_out[t] = bi;
 }
 
+// ---- overlap-average tiling (utils/util_image.py:889-979 ImageSpliterTh.update / gather) -----------------------------
+// acc[b,c,h0+y,w0+x] += tile[b,c,y,x];  count[h0+y,w0+x] += 1 (one plane: the reference's per-(b,c) counts are all equal)
+__global__ void tile_accumulate_kernel(float* acc, float* count, const float* tile, int B, int C, int H, int W, int h0, int w0, int th,
+                                       int tw) {
+    const long long n = (long long)B * C * th * tw;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(g % tw);
+        long long t = g / tw;
+        const int y = (int)(t % th);
+        const long long bc = t / th;
+        acc[(bc * H + h0 + y) * W + w0 + x] += tile[g];
+        if (bc == 0) count[(long long)(h0 + y) * W + w0 + x] += 1.0f;
+    }
+}
+__global__ void tile_finalize_kernel(float* acc, const float* count, long long BC, long long HW) {
+    const long long n = BC * HW;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x)
+        acc[g] = acc[g] / count[g % HW];
+}
+
 inline unsigned nblk(long long n, int bs = 256, long long cap = 65536) { return (unsigned)std::min<long long>((n + bs - 1) / bs, cap); }
 
 }  // namespace
@@ -201,6 +221,20 @@ int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int 
     const long long n = (long long)B * H * sf * W * sf * C;
     if (out_dt == RS_F16) hipLaunchKernelGGL((bicubic_up_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, B, C, H, W, sf, ldo);
     else hipLaunchKernelGGL((bicubic_up_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B, C, H, W, sf, ldo);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C, int H, int W, int h0, int w0, int th, int tw,
+                       void* stream) {
+    if (h0 < 0 || w0 < 0 || h0 + th > H || w0 + tw > W) return -2;
+    const long long n = (long long)B * C * th * tw;
+    hipLaunchKernelGGL(tile_accumulate_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, acc, count, tile, B, C, H, W, h0, w0, th, tw);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_tile_finalize(float* acc, const float* count, int B, int C, int H, int W, void* stream) {
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, acc, count, (long long)B * C, (long long)H * W);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

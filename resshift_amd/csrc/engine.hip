@@ -124,9 +124,16 @@ struct Exec {
     // every launch with hipEvents on the launch stream.
     struct Prof { bool on = false; std::vector<hipEvent_t> ev; size_t used = 0; } * prof = nullptr;
     double igemm_flops[2] = {0.0, 0.0};  // per input precision
+    double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
         igemm_flops[in_dt == RS_F16 ? 0 : 1] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
+        {
+            const double isz = in_dt == RS_F16 ? 2.0 : 4.0, osz = out_dt == RS_F16 ? 2.0 : 4.0;
+            const double src = (double)p.B * p.Hs * p.Ws * (double)(p.C0 + p.C1) * isz;
+            const double out = (double)p.M * p.Cout * osz;
+            igemm_bytes += (double)nz * (src + (double)p.Cout * p.Ktot * isz + out + (p.res ? out : 0.0));
+        }
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && prof->on) {
@@ -155,7 +162,7 @@ struct rs_engine {
     Arena arena;
     long long last_launches = 0;
     Exec::Prof prof;
-    double last_flops[2] = {0.0, 0.0}, last_igemm_ms = 0.0;
+    double last_flops[2] = {0.0, 0.0}, last_igemm_ms = 0.0, last_igemm_bytes = 0.0;
     long long last_igemm_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
@@ -928,6 +935,7 @@ struct rs_engine {
         fn(r);
         last_launches = r.launches;
         last_flops[0] = r.igemm_flops[0]; last_flops[1] = r.igemm_flops[1]; last_igemm_launches = r.igemm_launches;
+        last_igemm_bytes = r.igemm_bytes;
         last_igemm_ms = 0.0;
         if (prof.on && prof.used) {
             (void)hipStreamSynchronize(st);
@@ -1025,10 +1033,12 @@ size_t rs_arena_bytes(rs_engine* e) { return e ? e->arena.cap : 0; }
 // ---- profiling of the MFMA implicit-GEMM kernel family (bench.py roofline block)
 int rs_profile_enable(rs_engine* e, int on) { if (!e) return -1; e->prof.on = on != 0; return 0; }
 // out[0] = fp16-input igemm FLOPs of the last call, out[1] = fp32-input igemm FLOPs, out[2] = summed igemm kernel
-// time in ms (hipEvents on the launch stream; 0 unless profiling was enabled), out[3] = igemm launch count
+// time in ms (hipEvents on the launch stream; 0 unless profiling was enabled), out[3] = igemm launch count,
+// out[4] = algorithmic HBM bytes of those launches (each operand / result counted once)
 int rs_profile_get(rs_engine* e, double* out) {
     if (!e || !out) return -1;
     out[0] = e->last_flops[0]; out[1] = e->last_flops[1]; out[2] = e->last_igemm_ms; out[3] = (double)e->last_igemm_launches;
+    out[4] = e->last_igemm_bytes;
     return 0;
 }
 

@@ -250,9 +250,9 @@ class Engine:
 
     def profile_get(self) -> Dict[str, float]:
         """MFMA implicit-GEMM statistics of the last native call (see rs_profile_get)."""
-        out = (C.c_double * 4)()
+        out = (C.c_double * 5)()
         self.lib.rs_profile_get(self._h, out)
-        return {"flops_f16": out[0], "flops_f32": out[1], "igemm_ms": out[2], "igemm_launches": int(out[3])}
+        return {"flops_f16": out[0], "flops_f32": out[1], "igemm_ms": out[2], "igemm_launches": int(out[3]), "igemm_bytes": out[4]}
 
     def debug_enable(self, on: bool = True):
         self.lib.rs_debug_enable(self._h, int(on))

@@ -155,6 +155,28 @@ class ResShiftSampler(BaseSampler):
             results = results[:, :, : ori_h * self.sf, : ori_w * self.sf]
         return results.clamp_(-1.0, 1.0)
 
+    def sample_tiled(self, im_lq, mask=None, noise_repeat=False, tile_noises=None):
+        """sampler.py:176-216 (`_process_per_image`): inputs larger than `chop_size` are cut into overlapping
+        `chop_size` tiles (stride `chop_stride`, `chop_bs` tiles per sampler call), sampled independently and
+        overlap-averaged on the GPU; smaller inputs go straight to `sample_func`.  Returns [-1,1] like sample_func.
+        `tile_noises[k] = (noise, step_noises)` injects the draws of the k-th sampler call (parity runs)."""
+        from .tiling import TileSplitter
+
+        if not (im_lq.shape[2] > self.chop_size or im_lq.shape[3] > self.chop_size):
+            nz = tile_noises[0] if tile_noises else (None, None)
+            return self.sample_func(im_lq, noise_repeat=noise_repeat, mask=mask, noise=nz[0], step_noises=nz[1])
+        x = torch.cat([im_lq, mask], dim=1) if mask is not None else im_lq
+        splitter = TileSplitter(x, self.chop_size, stride=self.chop_stride, sf=self.sf, extra_bs=self.chop_bs)
+        for k, (pch, index_infos) in enumerate(splitter):
+            if mask is not None:
+                pch, mask_pch = pch[:, :-1].contiguous(), pch[:, -1:].contiguous()
+            else:
+                mask_pch = None
+            nz = tile_noises[k] if tile_noises else (None, None)
+            out = self.sample_func(pch, noise_repeat=noise_repeat, mask=mask_pch, noise=nz[0], step_noises=nz[1])
+            splitter.update(out, index_infos)
+        return splitter.gather()
+
     # ------------------------------------------------------------------ file-level demo driver
     @staticmethod
     def _read_image(path) -> torch.Tensor:
@@ -190,10 +212,8 @@ class ResShiftSampler(BaseSampler):
                 if mask_path is not None:
                     mask = torch.stack([self._read_image(Path(mask_path) / p.name)[:1] for p in mine]).to(self.device)
                     mask = (mask - 0.5) / 0.5
-                if lq.shape[2] > self.chop_size or lq.shape[3] > self.chop_size:
-                    raise NotImplementedError("tiled inference of large images is scheduled for a later round (SURVEY §8f-1)")
                 with ctx:
-                    sr = self.sample_func(lq, noise_repeat=noise_repeat, mask=mask)
+                    sr = self.sample_tiled(lq, mask=mask, noise_repeat=noise_repeat)
                 sr = sr * 0.5 + 0.5
                 if mask is not None and mask_back:
                     m01 = mask * 0.5 + 0.5

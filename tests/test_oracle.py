@@ -105,3 +105,35 @@ def test_spec_equals_reference_state_dict(cname):
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == list(spec.items())
     a = V(**ref_cfg["autoencoder"]["params"])
     assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == list(H.ae_param_spec(mine["autoencoder"]["params"]).items())
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_tiling_restatements_against_reference_ImageSpliterTh():
+    """The reference tiler cannot be imported (utils/util_image.py pulls cv2 / skimage), so its class source is exec'd as
+    is; the oracle's and the product's tile origin lists, and the oracle's sum/count averaging, must reproduce it."""
+    import os
+    import re
+
+    from resshift_amd.tiling import extract_starts
+
+    src = open(os.path.join(ref_import.REF, "utils", "util_image.py")).read()
+    m = re.search(r"^class ImageSpliterTh:.*?(?=^class |\Z)", src, re.S | re.M)
+    ns = {"torch": torch}
+    exec(m.group(0), ns)
+    Ref = ns["ImageSpliterTh"]
+    g = torch.Generator().manual_seed(0)
+    for (H, W, ps, st, sf, ebs) in [(96, 80, 64, 48, 4, 1), (130, 64, 64, 64, 2, 3), (64, 64, 64, 32, 4, 1), (200, 131, 64, 50, 1, 2)]:
+        im = torch.randn(2, 3, H, W, generator=g)
+        r = Ref(im, ps, st, sf=sf, extra_bs=ebs)
+        assert r.height_starts_list == oc.tile_starts(H, ps, st) == extract_starts(H, ps, st)
+        assert r.width_starts_list == oc.tile_starts(W, ps, st) == extract_starts(W, ps, st)
+        # feed a deterministic per-tile "result" through both accumulators
+        res = torch.zeros(2, 3, H * sf, W * sf)
+        cnt = torch.zeros_like(res)
+        for pch, infos in r:
+            out = torch.nn.functional.interpolate(pch, scale_factor=sf, mode="nearest") * 1.5 + 0.25
+            r.update(out, infos)
+            for t, (h0, h1, w0, w1) in enumerate(infos):
+                res[:, :, h0:h1, w0:w1] += out[t * 2:(t + 1) * 2]
+                cnt[:, :, h0:h1, w0:w1] += 1
+        assert torch.equal(r.gather(), res / cnt)
