@@ -30,6 +30,32 @@ __device__ __forceinline__ float rs_apply_act(float x, int act) {
     if (act == RS_ACT_SILU) return rs_silu(x);
     return x;
 }
+// Variants for fp16-STORAGE outputs: v_rcp_f32 / v_exp_f32 (1 ulp each) instead of the IEEE division sequence (12 VALU
+// instructions) and libm erff; their error is three orders of magnitude below the fp16 rounding of the stored value.
+// The fp32 ("exact") kernels never use them.
+__device__ __forceinline__ float rs_silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7); GELU(x) = x/2 + |x/2| * erf(|x|/sqrt 2)
+__device__ __forceinline__ float rs_gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float ex = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);   // exp(-z^2)
+    const float e = fmaf(-poly, ex, 1.0f);
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), e, hx);
+}
+// ACT is a compile-time constant here so that the element loops carry no per-value branches
+template <int ACT, bool FAST> __device__ __forceinline__ float rs_act_t(float x) {
+    if constexpr (ACT == RS_ACT_GELU) return FAST ? rs_gelu_fast(x) : rs_gelu(x);
+    else if constexpr (ACT == RS_ACT_SILU) return FAST ? rs_silu_fast(x) : rs_silu(x);
+    else return x;
+}
 
 template <typename T> struct Vec8;  // 8 consecutive elements of T
 template <> struct Vec8<f16> {
@@ -69,6 +95,7 @@ struct IGemmParams {
     int splitk;          // >1: grid.z slices K; fp32 partial slabs in `partial`, finished by splitk_reduce_kernel
     float* partial;      // [splitk][M][Cout] fp32 workspace (caller owned)
     unsigned x_bytes, w_bytes;  // extents of the x0 / w buffers for the igemm2 buffer descriptors (filled in by its launcher)
+    int sh_howo, sh_wo;         // log2(Ho*Wo), log2(Wo) when both are powers of two, else -1 (filled in by the igemm2 launcher)
 };
 
 struct DirectConvParams {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases (M0) are then pure SALU work
     const int lr = lane & 15, lg = lane >> 4;
     const int wp = wave % WPN, wc = wave / WPN;
     const int rr = 8 * wave + (lane >> 3);             // row inside a 64-row load round
@@ -127,10 +127,12 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     for (int i = 0; i < RX; ++i) {
         const int m = m0 + RND * i + rr;
         if (m < p.M) {
-            const int b = m / HoWo;
-            const int rem = m - b * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
+            int b, rem, oy, ox;
+            if (p.sh_wo >= 0) {   // power-of-two output planes (every layer of the shipped models): shifts, no divisions
+                b = m >> p.sh_howo; rem = m & (HoWo - 1); oy = rem >> p.sh_wo; ox = rem & (p.Wo - 1);
+            } else {
+                b = m / HoWo; rem = m - b * HoWo; oy = rem / p.Wo; ox = rem - oy * p.Wo;
+            }
             pixbase[i] = b * p.Hs * p.Ws;
             iy0[i] = oy * p.stride - p.pad_t;
             ix0[i] = ox * p.stride - p.pad_l;
@@ -160,10 +162,9 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     // Address generation is incremental: the per-row pixel byte offsets only change when this lane's K cursor crosses
     // into the next filter tap; between tap changes a stage costs one add per row.
     unsigned off[RX];
+    int ky = tap / p.KW, kx = tap - ky * p.KW;   // kept incrementally afterwards
     auto set_tap = [&]() {
         const bool kvalid = tap < ntaps;
-        const int ky = tap / p.KW;
-        const int kx = tap - ky * p.KW;
 #pragma unroll
         for (int i = 0; i < RX; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
         kk += BK;
         cc += BK;
         if (cc >= Ctot) {
-            do { cc -= Ctot; ++tap; } while (cc >= Ctot);
+            do {
+                cc -= Ctot; ++tap;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            } while (cc >= Ctot);
             set_tap();
         }
     };
@@ -247,35 +251,73 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     if constexpr (sizeof(TO) == 2) {
         constexpr int ROWB = (BC / 2) * 2 + 16;
         char* stg = smem + wave * (BP / WPN) * ROWB;
+        // The epilogue is VALU work that no MFMA overlaps inside this workgroup, so it is written as straight-line
+        // passes over the accumulators: (1) scale + bias with the bias fetched once per channel fragment, (2) the
+        // activation behind ONE uniform branch, (3) the residual as clamped (branch-free) vector loads issued together.
+        const bool quad = (p.Cout & 3) == 0;   // every 4-channel group is then entirely inside or outside the output
 #pragma unroll
-        for (int j = 0; j < FP; ++j) {
-            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+        for (int i = 0; i < FC; ++i) {
+            const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (quad) bv = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
+                else for (int r = 0; r < 4; ++r) bv[r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
+            }
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const int nl = i * 16 + lg * 4;
-                const int n = n0 + wc * (BC / 2) + nl;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.Cout) {
-                    if (n + 3 < p.Cout) { const f32x4 t = *(const f32x4*)(p.bias + n); bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3]; }
-                    else for (int r = 0; r < 4 && n + r < p.Cout; ++r) bv[r] = p.bias[n + r];
+            for (int j = 0; j < FP; ++j) acc[i][j] = acc[i][j] * p.out_scale + bv;
+        }
+        if (p.act == RS_ACT_GELU) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rs_gelu_fast(acc[i][j][r]);
+        } else if (p.act == RS_ACT_SILU) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rs_silu_fast(acc[i][j][r]);
+        }
+        if (res) {
+            if (res_vec && quad) {
+                f16x4 rv[FC][FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const long long mr = (long long)min(m0 + wp * (BP / WPN) + j * 16 + lr, p.M - 1) * p.ldres;
+#pragma unroll
+                    for (int i = 0; i < FC; ++i)
+                        rv[i][j] = *(const f16x4*)((const f16*)res + mr + min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4));
                 }
-                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = epi_act<TO>(fmaf(acc[i][j][r], p.out_scale, bv[r]), p.act);
-                if (res && m < p.M && n < p.Cout) {
-                    if (res_vec && n + 3 < p.Cout) {
-                        float rv[4];
-                        Out4<TO>::load(res + (long long)m * p.ldres + n, rv);
+                for (int i = 0; i < FC; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += (float)res[(long long)m * p.ldres + n + r];
+                    for (int j = 0; j < FP; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rv[i][j][r];
+            } else {
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) {
+                        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                        if (m < p.M)
+                            for (int r = 0; r < 4 && n + r < p.Cout; ++r) acc[i][j][r] += (float)res[(long long)m * p.ldres + n + r];
                     }
                 }
-                f16x4 h; h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
-                *(f16x4*)(stg + (j * 16 + lr) * ROWB + nl * 2) = h;
             }
         }
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                f16x4 h;
+                h[0] = (f16)acc[i][j][0]; h[1] = (f16)acc[i][j][1]; h[2] = (f16)acc[i][j][2]; h[3] = (f16)acc[i][j][3];
+                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+            }
         __syncthreads();
         constexpr int CPR = (BC / 2) / 8;
         constexpr int NITEM = (BP / WPN) * CPR;
@@ -349,6 +391,12 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    {
+        const int howo = p.Ho * p.Wo;
+        const bool pow2 = howo > 0 && (howo & (howo - 1)) == 0 && (p.Wo & (p.Wo - 1)) == 0;
+        p.sh_howo = pow2 ? __builtin_ctz(howo) : -1;
+        p.sh_wo = pow2 ? __builtin_ctz(p.Wo) : -1;
+    }
     hipLaunchKernelGGL((igemm2_kernel<TI, TO, BP, BC, NS, NWV>), dim3(tiles, 1, p.splitk > 1 ? p.splitk : nz), dim3(64 * NWV), lds, st, p);
     if (p.splitk > 1 && rs_splitk_reduce_launch(&p, sizeof(TO) == 2 ? RS_F16 : RS_F32, st) != 0) return hipErrorLaunchFailure;
     return hipGetLastError();

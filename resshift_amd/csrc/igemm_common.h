@@ -89,22 +89,10 @@ template <> struct Out4<float> {
     }
 };
 
-// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): used for fp16-storage outputs only, where it is three
-// orders of magnitude below the storage rounding; the fp32 path keeps libm's erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(t, poly, 1.421413741f);
-    poly = fmaf(t, poly, -0.284496736f);
-    poly = fmaf(t, poly, 0.254829592f);
-    poly *= t;
-    const float e = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
+// fp16-storage outputs use the v_rcp / v_exp formulations of common.h; the fp32 path keeps libm's erff and IEEE division
 template <typename TO> __device__ __forceinline__ float epi_act(float x, int act) {
-    if (act == RS_ACT_GELU) return sizeof(TO) == 2 ? gelu_fast(x) : rs_gelu(x);
-    if (act == RS_ACT_SILU) return rs_silu(x);
+    if (act == RS_ACT_GELU) return sizeof(TO) == 2 ? rs_gelu_fast(x) : rs_gelu(x);
+    if (act == RS_ACT_SILU) return sizeof(TO) == 2 ? rs_silu_fast(x) : rs_silu(x);
     return x;
 }
 

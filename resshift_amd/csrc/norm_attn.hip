@@ -69,6 +69,48 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
     }
 }
 
+// Element pass of the apply kernel.  Thread (pp, j) owns the 8-channel chunk j for good - its 16 affine coefficients
+// live in registers - and walks pixels pp, pp+PP, ...: no index divisions and no LDS reads in the loop, four 16-byte
+// loads in flight per thread.  ACT is compile-time (no per-element branches); fp16 storage uses the v_rcp/v_exp SiLU.
+template <typename T, int ACT>
+__device__ __forceinline__ void gn_apply_rows(const GNParams& p, const float* ca, const float* cb, int b) {
+    constexpr bool FAST = sizeof(T) == 2;
+    const int nchunk = p.C >> 3;
+    const int PP = 256 / nchunk;
+    const int tid = threadIdx.x;
+    const int j = tid % nchunk, pp = tid / nchunk;
+    if (pp >= PP) return;
+    float a[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = ca[j * 8 + e]; c[e] = cb[j * 8 + e]; }
+    const int nslab = gridDim.x;
+    const int pps = (p.HW + nslab - 1) / nslab;
+    const int p0 = blockIdx.x * pps;
+    const int p1 = min(p.HW, p0 + pps);
+    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + j * 8;
+    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy + j * 8;
+    int pix = p0 + pp;
+    for (; pix + 3 * PP < p1; pix += 4 * PP) {
+        Vec8<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].load(x + (long long)(pix + u * PP) * p.ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v[u].get(e), a[e], c[e])));
+            o.store(y + (long long)(pix + u * PP) * p.ldy);
+        }
+    }
+    for (; pix < p1; pix += PP) {
+        Vec8<T> v, o;
+        v.load(x + (long long)pix * p.ldx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v.get(e), a[e], c[e])));
+        o.store(y + (long long)pix * p.ldy);
+    }
+}
+
 // apply: grid (S2, B).  y = act( ((x-mean)*rstd*gamma+beta) * (1+scale) + shift )
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
@@ -116,44 +158,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
         ca[c] = a; cb[c] = bb;
     }
     __syncthreads();
-    const int nchunk = p.C >> 3;
-    const int nslab = gridDim.x;
-    const int pps = (p.HW + nslab - 1) / nslab;
-    const int p0 = blockIdx.x * pps;
-    const int p1 = min(p.HW, p0 + pps);
-    const long long nitem = (long long)max(0, p1 - p0) * nchunk;
-    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx;
-    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy;
-    // 4 items per thread per trip: all loads are issued before the first use
-    long long it = tid;
-    for (; it + 3 * 256 < nitem; it += 4 * 256) {
-        Vec8<T> v[4];
-        int pixs[4], c0s[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long q = it + u * 256;
-            pixs[u] = p0 + (int)(q / nchunk);
-            c0s[u] = (int)(q % nchunk) * 8;
-            v[u].load(x + (long long)pixs[u] * p.ldx + c0s[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            Vec8<T> o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.set(e, rs_apply_act(fmaf(v[u].get(e), ca[c0s[u] + e], cb[c0s[u] + e]), p.act));
-            o.store(y + (long long)pixs[u] * p.ldy + c0s[u]);
-        }
-    }
-    for (; it < nitem; it += 256) {
-        const int pix = p0 + (int)(it / nchunk);
-        const int c0 = (int)(it % nchunk) * 8;
-        Vec8<T> v;
-        v.load(x + (long long)pix * p.ldx + c0);
-        Vec8<T> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, rs_apply_act(fmaf(v.get(e), ca[c0 + e], cb[c0 + e]), p.act));
-        o.store(y + (long long)pix * p.ldy + c0);
-    }
+    if (p.act == RS_ACT_SILU) gn_apply_rows<T, RS_ACT_SILU>(p, ca, cb, b);
+    else if (p.act == RS_ACT_GELU) gn_apply_rows<T, RS_ACT_GELU>(p, ca, cb, b);
+    else gn_apply_rows<T, RS_ACT_NONE>(p, ca, cb, b);
 }
 
 }  // namespace

@@ -47,6 +47,9 @@ SHAPES = [
     ("ae c3 256->128 @256", 256, 256, 128, 3, 1, 1, 0, 0, 1),
     ("ae q 512->512 @64 (1x1)", 64, 512, 512, 1, 1, 1, 0, 0, 8),
 ]
+only = [t for t in os.environ.get("RS_BENCH_ONLY", "").split(",") if t]   # substring filter on the shape names
+if only:
+    SHAPES = [sh for sh in SHAPES if any(t in sh[0] for t in only)]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 st = _lib.current_stream_ptr()
