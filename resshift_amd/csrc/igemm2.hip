@@ -10,6 +10,7 @@
 //     that every wave issues exactly L loads per stage and the counted waits stay valid.
 #include "igemm_common.h"
 #include <algorithm>
+#include <type_traits>
 
 extern "C" int rs_splitk_reduce_launch(const IGemmParams* p, int out_dt, hipStream_t st);
 
@@ -77,7 +78,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename TI, typename TO, int BP, int BC, int NS, int NWV>
-__global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
+// second launch bound = waves per SIMD the register allocation must allow: the 2-stage 128-pixel variant lives on TWO
+// co-resident workgroups per CU (4 waves per SIMD, <= 128 VGPRs); one spilled-over register halves its occupancy
+__global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NWV == 16) ? 4 : 2) void igemm2_kernel(IGemmParams p) {
     constexpr int WPN = NWV / 2;               // pixel-waves (x 2 channel-waves)
     constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
     constexpr int CH = MfmaOps<TI>::CH;
@@ -251,73 +254,56 @@ __global__ __launch_bounds__(64 * NWV) void igemm2_kernel(IGemmParams p) {
     if constexpr (sizeof(TO) == 2) {
         constexpr int ROWB = (BC / 2) * 2 + 16;
         char* stg = smem + wave * (BP / WPN) * ROWB;
-        // The epilogue is VALU work that no MFMA overlaps inside this workgroup, so it is written as straight-line
-        // passes over the accumulators: (1) scale + bias with the bias fetched once per channel fragment, (2) the
-        // activation behind ONE uniform branch, (3) the residual as clamped (branch-free) vector loads issued together.
+        // The epilogue is VALU work that no MFMA overlaps inside this workgroup, so it is kept lean: the residual is
+        // fetched up front with clamped (branch-free) vector loads that fly during the arithmetic, the bias once per
+        // channel fragment, the activation is a compile-time choice behind ONE uniform branch, and fragments are
+        // finished one at a time (sched_barrier) so that the register allocation stays within the 128 VGPRs that two
+        // co-resident workgroups per CU allow.
         const bool quad = (p.Cout & 3) == 0;   // every 4-channel group is then entirely inside or outside the output
+        const bool res_fast = res && res_vec && quad;
+        f16x4 rv[FC][FP];
+        if (res_fast) {
 #pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                if (quad) bv = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
-                else for (int r = 0; r < 4; ++r) bv[r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < FP; ++j) acc[i][j] = acc[i][j] * p.out_scale + bv;
-        }
-        if (p.act == RS_ACT_GELU) {
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rs_gelu_fast(acc[i][j][r]);
-        } else if (p.act == RS_ACT_SILU) {
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = rs_silu_fast(acc[i][j][r]);
-        }
-        if (res) {
-            if (res_vec && quad) {
-                f16x4 rv[FC][FP];
-#pragma unroll
-                for (int j = 0; j < FP; ++j) {
-                    const long long mr = (long long)min(m0 + wp * (BP / WPN) + j * 16 + lr, p.M - 1) * p.ldres;
-#pragma unroll
-                    for (int i = 0; i < FC; ++i)
-                        rv[i][j] = *(const f16x4*)((const f16*)res + mr + min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4));
-                }
+            for (int j = 0; j < FP; ++j) {
+                const long long mr = (long long)min(m0 + wp * (BP / WPN) + j * 16 + lr, p.M - 1) * p.ldres;
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rv[i][j][r];
-            } else {
-#pragma unroll
-                for (int j = 0; j < FP; ++j) {
-                    const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
-#pragma unroll
-                    for (int i = 0; i < FC; ++i) {
-                        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-                        if (m < p.M)
-                            for (int r = 0; r < 4 && n + r < p.Cout; ++r) acc[i][j][r] += (float)res[(long long)m * p.ldres + n + r];
-                    }
-                }
+                    rv[i][j] = *(const f16x4*)((const f16*)res + mr + min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4));
             }
         }
-#pragma unroll
-        for (int j = 0; j < FP; ++j)
+        auto finish = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
-                f16x4 h;
-                h[0] = (f16)acc[i][j][0]; h[1] = (f16)acc[i][j][1]; h[2] = (f16)acc[i][j][2]; h[3] = (f16)acc[i][j][3];
-                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    if (quad) bv = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
+                    else for (int r = 0; r < 4; ++r) bv[r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    f32x4 v = acc[i][j] * p.out_scale + bv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
+                    if (res_fast) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                    } else if (res) {
+                        const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+                        if (m < p.M)
+                            for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += (float)res[(long long)m * p.ldres + n + r];
+                    }
+                    f16x4 h;
+                    h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
+                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        };
+        if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
+        else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
+        else finish(std::integral_constant<int, RS_ACT_NONE>{});
         __syncthreads();
         constexpr int CPR = (BC / 2) / 8;
         constexpr int NITEM = (BP / WPN) * CPR;
