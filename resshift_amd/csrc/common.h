@@ -96,6 +96,7 @@ struct IGemmParams {
     float* partial;      // [splitk][M][Cout] fp32 workspace (caller owned)
     unsigned x_bytes, w_bytes;  // extents of the x0 / w buffers for the igemm2 buffer descriptors (filled in by its launcher)
     int sh_howo, sh_wo;         // log2(Ho*Wo), log2(Wo) when both are powers of two, else -1 (filled in by the igemm2 launcher)
+    int dbg;                    // timing ablations (RS_IGEMM_DBG): 1 = no operand loads after the prologue, 2 = no ds_read/MFMA, 4 = no barriers
 };
 
 struct DirectConvParams {

@@ -361,6 +361,8 @@ hipError_t launch_t(const IGemmParams& p, int nz, hipStream_t st) {
 
 extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int* BC);
 extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, int BP, int BC, int nz, hipStream_t st);
+extern "C" int rs_igemm3_pick(int M, int Cout, int Ktot, int in_dt, int nz, int splitk, int* BC);
+extern "C" int rs_igemm3_launch(const IGemmParams* pp, int out_dt, int BC, hipStream_t st);
 
 extern "C" int rs_splitk_reduce_launch(const IGemmParams* pp, int out_dt, hipStream_t st) {
     const IGemmParams& p = *pp;
@@ -403,6 +405,9 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
     int bp2 = 0, bc2 = 0;
+    // third generation (256-pixel tiles, one workgroup per CU, register-pipelined fragments) for the long-K fp16 layers that fill the chip
+    int bc3 = 0;
+    if (use_v2 && p.C1 == 0 && (out_dt == RS_F16 || out_dt == RS_F32) && rs_igemm3_pick(p.M, p.Cout, p.Ktot, in_dt, nz, p.splitk, &bc3)) return rs_igemm3_launch(&p, out_dt, bc3, st);
     if (use_v2 && p.C1 == 0 && rs_igemm2_pick(p.M, p.Cout, p.Ktot * (in_dt == RS_F16 ? 2 : 4), nz * p.splitk, &bp2, &bc2)) return rs_igemm2_launch(&p, in_dt, out_dt, bp2, bc2, nz, st);
     hipError_t e;
     if (in_dt == RS_F16 && out_dt == RS_F16) e = launch_t<f16, f16>(p, nz, st);

@@ -221,11 +221,11 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
             const int later = min(NS - 2, nk - 1 - kt);   // stages issued after kt that may still be in flight
             if (later >= 2) wait_vmcnt<2 * L>(); else if (later == 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
         // refill the slot every wave finished reading before this barrier
-        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS);
+        if (kt + NS - 1 < nk && !(p.dbg & 1)) issue((kt + NS - 1) % NS);
         const char* sb = smem + (kt % NS) * STAGE;
-        Stage2<TI, FC, FP>::run(sb + la + swz0, sb + la + swz1, sb + lb + swz0, sb + lb + swz1, acc);
+        if (!(p.dbg & 2)) Stage2<TI, FC, FP>::run(sb + la + swz0, sb + la + swz1, sb + lb + swz0, sb + lb + swz1, acc);
     }
     __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
 
@@ -377,6 +377,7 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    { static const int dbg = []() { const char* e = getenv("RS_IGEMM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     {
         const int howo = p.Ho * p.Wo;
         const bool pow2 = howo > 0 && (howo & (howo - 1)) == 0 && (p.Wo & (p.Wo - 1)) == 0;

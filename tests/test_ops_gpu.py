@@ -90,6 +90,12 @@ BIG_CONV_CASES = [
     (16, 32, 32, 320, 320, 3, 2, 0, False),   # nearest-x2 upsample folded, 256-pixel tiles
     (4, 128, 128, 128, 128, 3, 1, 0, True),   # AE level: BC=128, 3-stage ring, 256-pixel tiles
     (9, 60, 52, 160, 320, 3, 1, 0, False),    # ragged M (not a multiple of the tile), two channel tiles
+    # third-generation kernel (igemm3.hip: 256-pixel tiles, 224..320 tiles, K >= 1024, Cout % 160 == 0 or % 128 == 0);
+    # (16,64,64,160,160) and (4,128,128,128,128) above are in its range as well
+    (10, 60, 52, 160, 320, 3, 1, 0, True),    # ragged M, non-power-of-two planes (division path), residual, BC=160
+    (8, 32, 32, 320, 320, 3, 2, 0, False),    # nearest-x2 upsample folded
+    (16, 32, 32, 320, 640, 3, 1, 1, False),   # four channel tiles, GELU epilogue
+    (2, 128, 128, 256, 256, 3, 1, 2, True),   # BC=128, SiLU epilogue + residual
 ]
 
 
@@ -112,6 +118,8 @@ def test_conv_igemm2_large(gpu, dtype, case):
     ref = F.conv2d(xr, w.to(dtype).float(), b, padding=k // 2)
     if act == 1:
         ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.silu(ref)
     res_d = None
     if use_res:
         res_d = _nhwc(torch.randn(ref.shape, generator=g), dtype, gpu)
