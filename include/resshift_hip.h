@@ -128,6 +128,16 @@ int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C
                        void* stream);
 int rs_tile_finalize(float* acc, const float* count, int B, int C, int H, int W, void* stream);
 
+/* uint8 pre / post processing on the device.
+ * rs_u8_to_input:  interleaved uint8 [B,H,W,C] -> planar fp32 [B,C,H,W] in [-1,1]  ((v/255 - 0.5)/0.5; replaces
+ *                  datapipe/datasets.py:59-63 ToTensor + Normalize on the host)
+ * rs_output_to_u8: planar fp32 [-1,1] -> interleaved uint8: x*0.5+0.5, optional inpainting blend with the LQ input
+ *                  sr*m + lq*(1-m) (sampler.py:218-222; lq and mask both null or both set, mask is [B,1,H,W] in [-1,1]),
+ *                  clamp, *255, round-half-even, RGB->BGR when `bgr` (utils/util_image.py:245-269 tensor2img) */
+int rs_u8_to_input(const void* src_u8_nhwc, float* dst_f32_nchw, int B, int H, int W, int C, void* stream);
+int rs_output_to_u8(const float* sr_f32_nchw, const float* lq_f32_nchw, const float* mask_f32_n1hw, void* dst_u8_nhwc, int B, int H,
+                    int W, int C, int bgr, void* stream);
+
 /* ---- introspection --------------------------------------------------------------------------- */
 /* bytes of scratch arena currently allocated; number of kernel launches issued by the last call */
 size_t rs_arena_bytes(rs_engine* e);

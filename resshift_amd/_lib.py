@@ -85,6 +85,8 @@ SIGNATURES = {
     "rs_axpbypcz": (_I, [_P, _P, _P, _P, _F, _F, _F, _LL, _P]),
     "rs_tile_accumulate": (_I, [_P, _P, _P] + [_I] * 8 + [_P]),
     "rs_tile_finalize": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "rs_u8_to_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "rs_output_to_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rs_arena_bytes": (_SZ, [_P]),
     "rs_last_launch_count": (_LL, [_P]),
     "rs_profile_enable": (_I, [_P, _I]),

@@ -179,6 +179,41 @@ inline unsigned nblk(long long n, int bs = 256, long long cap = 65536) { return 
 
 }  // namespace
 
+// ---------------------------------------------------------------- uint8 pre / post processing on the device
+// pre:  datapipe/datasets.py:59-63 (ToTensor + Normalize(0.5, 0.5)): interleaved uint8 HWC -> planar fp32 in [-1, 1].
+// post: sampler.py:218-222 + utils/util_image.py:245-269 (tensor2img): x*0.5+0.5, optional inpainting blend
+//       sr*m + lq*(1-m), clamp to [0,1], *255, round half to even, optional RGB->BGR, planar fp32 -> interleaved uint8.
+// The arithmetic is spelled with the non-contracting intrinsics so that it rounds exactly like the reference's
+// separate torch / numpy ops (no fused multiply-add).
+__global__ void u8_to_input_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long npix, int HW, int C) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {   // pixel of B*H*W
+        const long long b = i / HW, hw = i - b * HW;
+        for (int c = 0; c < C; ++c) {
+            const float v = __fdiv_rn((float)src[i * C + c], 255.0f);
+            dst[(b * C + c) * HW + hw] = __fdiv_rn(__fsub_rn(v, 0.5f), 0.5f);
+        }
+    }
+}
+
+__global__ void output_to_u8_kernel(const float* __restrict__ sr, const float* __restrict__ lq, const float* __restrict__ mask,
+                                    unsigned char* __restrict__ dst, long long npix, int HW, int C, int bgr) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, hw = i - b * HW;
+        float m = 1.0f;
+        if (mask) m = __fadd_rn(__fmul_rn(mask[b * HW + hw], 0.5f), 0.5f);
+        for (int c = 0; c < C; ++c) {
+            float v = __fadd_rn(__fmul_rn(sr[(b * C + c) * HW + hw], 0.5f), 0.5f);
+            if (mask) {
+                const float l = __fadd_rn(__fmul_rn(lq[(b * C + c) * HW + hw], 0.5f), 0.5f);
+                v = __fadd_rn(__fmul_rn(v, m), __fmul_rn(l, __fsub_rn(1.0f, m)));
+            }
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            const int oc = (bgr && C == 3) ? 2 - c : c;
+            dst[i * C + oc] = (unsigned char)rintf(__fmul_rn(v, 255.0f));
+        }
+    }
+}
+
 extern "C" {
 
 int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C, int HW, int ldo, int coff, float scale, hipStream_t st) {
@@ -235,6 +270,22 @@ int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C
 int rs_tile_finalize(float* acc, const float* count, int B, int C, int H, int W, void* stream) {
     const long long n = (long long)B * C * H * W;
     hipLaunchKernelGGL(tile_finalize_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, acc, count, (long long)B * C, (long long)H * W);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_u8_to_input(const void* src_u8_nhwc, float* dst_f32_nchw, int B, int H, int W, int C, void* stream) {
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(u8_to_input_kernel, dim3(nblk(npix)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8_nhwc, dst_f32_nchw,
+                       npix, H * W, C);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_output_to_u8(const float* sr_f32_nchw, const float* lq_f32_nchw, const float* mask_f32_n1hw, void* dst_u8_nhwc, int B, int H, int W,
+                    int C, int bgr, void* stream) {
+    if ((mask_f32_n1hw != nullptr) != (lq_f32_nchw != nullptr)) return -2;
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(output_to_u8_kernel, dim3(nblk(npix)), dim3(256), 0, (hipStream_t)stream, sr_f32_nchw, lq_f32_nchw, mask_f32_n1hw,
+                       (unsigned char*)dst_u8_nhwc, npix, H * W, C, bgr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

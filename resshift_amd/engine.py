@@ -206,6 +206,28 @@ class Engine:
         self._chk(rc, "rs_axpbypcz")
         return out
 
+    def u8_to_input(self, img_u8):
+        """uint8 [B,H,W,C] device tensor -> fp32 [B,C,H,W] in [-1,1] (datapipe/datasets.py:59-63 on the device)."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.is_cuda
+        img_u8 = img_u8.contiguous()
+        B, H, W, Cc = img_u8.shape
+        out = torch.empty(B, Cc, H, W, device=img_u8.device, dtype=torch.float32)
+        self._chk(self.lib.rs_u8_to_input(img_u8.data_ptr(), out.data_ptr(), B, H, W, Cc, self._stream()), "rs_u8_to_input")
+        return out
+
+    def output_to_u8(self, sr, lq=None, mask=None, bgr=False):
+        """fp32 [B,C,H,W] in [-1,1] -> uint8 [B,H,W,C]; with `lq` and `mask` ([B,1,H,W] in [-1,1]) the inpainting blend
+        of sampler.py:218-222 is applied first; rounding as utils/util_image.py:245-269 (tensor2img)."""
+        sr = self._f32c(sr)
+        B, Cc, H, W = sr.shape
+        lq_t = self._f32c(lq) if lq is not None else None
+        mk_t = self._f32c(mask) if mask is not None else None
+        out = torch.empty(B, H, W, Cc, device=sr.device, dtype=torch.uint8)
+        rc = self.lib.rs_output_to_u8(sr.data_ptr(), lq_t.data_ptr() if lq_t is not None else None, mk_t.data_ptr() if mk_t is not None else None,
+                                      out.data_ptr(), B, H, W, Cc, int(bool(bgr)), self._stream())
+        self._chk(rc, "rs_output_to_u8")
+        return out
+
     def sample(self, y, noise, tables: Dict[str, np.ndarray], sf: int, scale_factor: float, mask=None, prec_unet=F16, prec_encode=F16,
                prec_decode=F16, return_aux=False):
         """The whole p_sample_loop in one native call.  noise: [steps+1,B,Cz,hz,wz] fp32 in draw order."""

@@ -63,8 +63,9 @@ def reload_model(model: torch.nn.Module, ckpt: Mapping[str, torch.Tensor]) -> No
 
 class BaseSampler:
     def __init__(self, configs, sf=4, use_amp=True, chop_size=128, chop_stride=128, chop_bs=1, padding_offset=16, seed=10000,
-                 state_dicts: Optional[Mapping[str, Mapping[str, torch.Tensor]]] = None):
-        """`state_dicts` ({"model": sd, "autoencoder": sd}) replaces checkpoint files, e.g. for synthetic-weight runs."""
+                 state_dicts: Optional[Mapping[str, Mapping[str, torch.Tensor]]] = None, blob_cache=None):
+        """`state_dicts` ({"model": sd, "autoencoder": sd}) replaces checkpoint files, e.g. for synthetic-weight runs.
+        `blob_cache`: file that keeps the packed device weights between runs (sharding.build_engine_with_broadcast)."""
         self.configs = configs if isinstance(configs, Mapping) else load_config(configs)
         self.sf = sf
         self.chop_size, self.chop_stride, self.chop_bs = chop_size, chop_stride, chop_bs
@@ -72,6 +73,7 @@ class BaseSampler:
         self.use_amp = use_amp
         self.padding_offset = padding_offset
         self._state_dicts = state_dicts
+        self._blob_cache = blob_cache
         self.setup_dist()
         self.setup_seed()
         self.build_model()
@@ -112,7 +114,7 @@ class BaseSampler:
         eng = sharding.build_engine_with_broadcast(
             model, autoencoder,
             load_fn=lambda: (self._load_sd("model", c["model"].get("ckpt_path")), self._load_sd("autoencoder", c["autoencoder"].get("ckpt_path"))),
-            rank=self.rank, world=self.num_gpus)
+            rank=self.rank, world=self.num_gpus, blob_cache=self._blob_cache)
         self.base_diffusion.adopt_engine(model, autoencoder, eng)
         self.model = model.eval()
         self.autoencoder = autoencoder.eval()
@@ -179,46 +181,39 @@ class ResShiftSampler(BaseSampler):
 
     # ------------------------------------------------------------------ file-level demo driver
     @staticmethod
-    def _read_image(path) -> torch.Tensor:
+    def _read_image_u8(path, gray=False) -> torch.Tensor:
+        """uint8 HWC tensor (RGB, or one channel for masks); decoding is host work, everything after it runs on the GPU."""
         from PIL import Image
 
-        im = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
-        return torch.from_numpy(im).permute(2, 0, 1).contiguous()
-
-    @staticmethod
-    def _write_image(t: torch.Tensor, path) -> None:
-        from PIL import Image
-
-        arr = (t.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0).round().astype(np.uint8)
-        Image.fromarray(arr).save(path)
+        im = np.asarray(Image.open(path).convert("L" if gray else "RGB"), dtype=np.uint8)
+        return torch.from_numpy(im.reshape(im.shape[0], im.shape[1], -1).copy())
 
     def inference(self, in_path, out_path, mask_path=None, mask_back=True, bs=1, noise_repeat=False):
-        """sampler.py:167-308 for inputs that fit one pass (H, W <= chop_size): batches of `bs` images are
-        sharded over the ranks exactly like sampler.py:273-277; every rank writes its own PNGs."""
+        """sampler.py:167-308: batches of `bs` images are sharded over the ranks exactly like sampler.py:273-277; every
+        rank writes its own PNGs.  uint8 -> [-1,1] (datapipe/datasets.py:59-63), the inpainting blend (sampler.py:218-222)
+        and the final clamp / round to uint8 (utils/util_image.py:245-269) run on the device (rs_u8_to_input /
+        rs_output_to_u8): only uint8 pixels cross PCIe.  Inputs larger than `chop_size` take the tiled path."""
         in_path, out_path = Path(in_path), Path(out_path)
         if self.rank == 0:
             out_path.mkdir(parents=True, exist_ok=True)
         sharding.barrier()
         files = sorted([p for p in (in_path.glob("*") if in_path.is_dir() else [in_path])
                         if p.suffix.lower() in (".png", ".jpg", ".jpeg", ".bmp")])
-        ctx = torch.autocast("cuda") if (self.use_amp and torch.cuda.is_available()) else nullcontext()
+        from PIL import Image
+
         for b0 in range(0, len(files), bs):
             batch = files[b0:b0 + bs]
             lo, hi = sharding.shard_bounds(len(batch), self.rank, self.num_gpus)
             mine = batch[lo:hi]
             if mine:
-                lq = torch.stack([(self._read_image(p) - 0.5) / 0.5 for p in mine]).to(self.device)
+                lq = self.engine.u8_to_input(torch.stack([self._read_image_u8(p) for p in mine]).to(self.device))
                 mask = None
                 if mask_path is not None:
-                    mask = torch.stack([self._read_image(Path(mask_path) / p.name)[:1] for p in mine]).to(self.device)
-                    mask = (mask - 0.5) / 0.5
-                with ctx:
-                    sr = self.sample_tiled(lq, mask=mask, noise_repeat=noise_repeat)
-                sr = sr * 0.5 + 0.5
-                if mask is not None and mask_back:
-                    m01 = mask * 0.5 + 0.5
-                    sr = sr * m01 + (lq * 0.5 + 0.5) * (1 - m01)
-                for p, im in zip(mine, sr):
-                    self._write_image(im, out_path / f"{p.stem}.png")
+                    mask = self.engine.u8_to_input(torch.stack([self._read_image_u8(Path(mask_path) / p.name, gray=True) for p in mine]).to(self.device))
+                sr = self.sample_tiled(lq, mask=mask, noise_repeat=noise_repeat)
+                blend = mask is not None and mask_back
+                out_u8 = self.engine.output_to_u8(sr, lq=lq if blend else None, mask=mask if blend else None).cpu().numpy()
+                for p, im in zip(mine, out_u8):
+                    Image.fromarray(im if im.shape[2] != 1 else im[:, :, 0]).save(out_path / f"{p.stem}.png")
         sharding.barrier()
         self.write_log(f"Processing done, enjoy the results in {out_path}")

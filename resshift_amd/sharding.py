@@ -94,20 +94,57 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return F.pad(x, pad=(0, pad_w, 0, pad_h), mode="reflect")
 
 
-def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int):
+BLOB_CACHE_MAGIC = b"RSBLOB02"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+
+
+def _blob_cache_load(path, eng) -> bool:
+    """Fill the engine's device blob from a packed-blob cache file; False when absent / stale (size or magic)."""
+    if not path or not os.path.exists(path):
+        return False
+    blob = eng.weight_blob()
+    with open(path, "rb") as fh:
+        head = fh.read(16)
+        if head[:8] != BLOB_CACHE_MAGIC or int.from_bytes(head[8:16], "little") != blob.numel():
+            return False
+        import numpy as np
+
+        data = np.fromfile(fh, dtype=np.uint8, count=blob.numel())
+    if data.size != blob.numel():
+        return False
+    blob.copy_(torch.from_numpy(data))
+    return True
+
+
+def _blob_cache_save(path, eng) -> None:
+    blob = eng.weight_blob().cpu().numpy()
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        fh.write(BLOB_CACHE_MAGIC + int(blob.size).to_bytes(8, "little"))
+        blob.tofile(fh)
+    os.replace(tmp, path)
+
+
+def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int, blob_cache=None):
     """Create the fused UNet+AE engine on this rank's GPU.  Rank 0 calls `load_fn()` -> (unet_sd, ae_sd), fills the
-    drop-in modules (reload_model semantics) and packs the device blob; the blob is then broadcast."""
+    drop-in modules (reload_model semantics) and packs the device blob; the blob is then broadcast.
+
+    `blob_cache`: path of a packed-blob file.  When it exists (and matches this configuration's blob size) rank 0 uploads
+    it instead of reading and repacking the checkpoints - the drop-in modules then keep their initial parameters, only
+    the engine owns the real weights; otherwise the freshly packed blob is written there for the next start."""
     from .engine import Engine
     from .sampler import reload_model
 
     dev = next(model.parameters()).device
     eng = Engine(unet_params=model.params, ae_params=autoencoder.params, device=dev)
-    if rank == 0:
+    if rank == 0 and not _blob_cache_load(blob_cache, eng):
         unet_sd, ae_sd = load_fn()
         with torch.no_grad():
             reload_model(model, unet_sd)
             reload_model(autoencoder, ae_sd)
         eng.load_state_dicts(unet_sd=model.state_dict(), ae_sd=autoencoder.state_dict())
+        if blob_cache:
+            torch.cuda.synchronize(dev)
+            _blob_cache_save(blob_cache, eng)
     if world > 1:
         torch.cuda.synchronize(dev)
         broadcast_blob(eng.weight_blob(), src=0)

@@ -228,3 +228,94 @@ def test_tiled_large_image_path(gpu):
     p = H.psnr(out.cpu(), ref)
     print(f"tiled path: {n_tiles} tiles in {n_calls} calls, PSNR {p:.1f} dB")
     assert p >= 60.0
+
+
+def test_u8_pre_and_post_processing_on_device(gpu):
+    """rs_u8_to_input / rs_output_to_u8 against the reference's host arithmetic (datapipe/datasets.py:59-63,
+    sampler.py:218-222, utils/util_image.py:245-269): bit-exact, incl. the inpainting blend and the BGR order."""
+    from resshift_amd.engine import Engine
+
+    up, ap, _, _ = H.CASES["tiny"]
+    eng = Engine(unet_params=up, ae_params=ap, device=gpu)
+    g = torch.Generator().manual_seed(11)
+    im = torch.randint(0, 256, (3, 20, 28, 3), generator=g, dtype=torch.uint8)
+    x = eng.u8_to_input(im.to(gpu)).cpu()
+    ref = ((im.float() / 255.0) - 0.5) / 0.5
+    assert torch.equal(x, ref.permute(0, 3, 1, 2).contiguous())
+    sr = torch.randn(3, 3, 20, 28, generator=g) * 0.8
+    mask = ((torch.rand(3, 1, 20, 28, generator=g) > 0.6).float() - 0.5) / 0.5
+
+    def host_post(sr, lq=None, mask=None):
+        t = sr * 0.5 + 0.5
+        if mask is not None:
+            m = mask * 0.5 + 0.5
+            t = t * m + (lq * 0.5 + 0.5) * (1 - m)
+        return torch.from_numpy(np.round(t.clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255.0).astype(np.uint8))
+
+    assert torch.equal(eng.output_to_u8(sr.to(gpu)).cpu(), host_post(sr))
+    assert torch.equal(eng.output_to_u8(sr.to(gpu), lq=x.to(gpu), mask=mask.to(gpu)).cpu(), host_post(sr, x, mask))
+    assert torch.equal(eng.output_to_u8(sr.to(gpu), bgr=True).cpu(), host_post(sr).flip(-1))
+    gray = torch.rand(2, 1, 9, 7, generator=g) * 2 - 1
+    assert torch.equal(eng.output_to_u8(gray.to(gpu)).cpu(), host_post(gray))
+
+
+def _tiny_cfg(up, ap, dp, unet_ckpt=None, ae_ckpt=None):
+    from resshift_amd.config import ConfigNode
+
+    return ConfigNode(model=ConfigNode(target="models.unet.UNetModelSwin", ckpt_path=unet_ckpt, params=up),
+                      diffusion=ConfigNode(target="models.script_util.create_gaussian_diffusion", params=dp),
+                      autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=ae_ckpt, params=ap))
+
+
+def test_checkpoint_ingestion_and_blob_cache(gpu, tmp_path):
+    """.pth files as the reference ships them ({"state_dict": ...}, DDP `module.` prefix; sampler.py:106-117,
+    utils/util_net.py:86-98) -> same samples as in-memory state_dicts; a second start from the packed-blob cache never
+    opens the checkpoints."""
+    from resshift_amd import ResShiftSampler
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    torch.save({"state_dict": {"module." + k: v for k, v in usd.items()}}, tmp_path / "unet.pth")
+    torch.save(dict(asd), tmp_path / "ae.pth")
+    y, noises, _ = H.synth.synthetic_inputs(5, 2, 16, 16, 3, 16, 16, dp["steps"])
+    kw = dict(sf=4, use_amp=False, padding_offset=16, seed=1)
+
+    def run(s):
+        o = s.sample_func(y.to(gpu), noise=noises[0].to(gpu), step_noises=[n.to(gpu) for n in noises[1:]])
+        torch.cuda.synchronize()
+        return o.cpu()
+
+    ref = run(ResShiftSampler(_tiny_cfg(up, ap, dp), state_dicts={"model": usd, "autoencoder": asd}, **kw))
+    cache = tmp_path / "weights.rsblob"
+    got = run(ResShiftSampler(_tiny_cfg(up, ap, dp, str(tmp_path / "unet.pth"), str(tmp_path / "ae.pth")), blob_cache=str(cache), **kw))
+    assert torch.equal(got, ref)
+    assert cache.exists() and cache.stat().st_size > 1000
+    again = run(ResShiftSampler(_tiny_cfg(up, ap, dp, "/nonexistent/unet.pth", "/nonexistent/ae.pth"), blob_cache=str(cache), **kw))
+    assert torch.equal(again, ref)
+    cache.write_bytes(cache.read_bytes()[:-7])  # truncated cache -> ignored, falls back to the checkpoints
+    with pytest.raises((FileNotFoundError, OSError)):
+        ResShiftSampler(_tiny_cfg(up, ap, dp, "/nonexistent/unet.pth", "/nonexistent/ae.pth"), blob_cache=str(cache), **kw)
+
+
+def test_inference_files_on_device_uint8(gpu, tmp_path):
+    """ResShiftSampler.inference (sampler.py:167-308): PNG in -> PNG out, one input larger than chop_size (tiled path)."""
+    from PIL import Image
+    from resshift_amd import ResShiftSampler
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    s = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, chop_size=16, chop_stride=12, chop_bs=2, padding_offset=16, seed=3,
+                        state_dicts={"model": usd, "autoencoder": asd})
+    g = torch.Generator().manual_seed(2)
+    (tmp_path / "in").mkdir()
+    ims = {"a": torch.randint(0, 256, (16, 16, 3), generator=g, dtype=torch.uint8),
+           "b": torch.randint(0, 256, (24, 20, 3), generator=g, dtype=torch.uint8)}
+    for k, v in ims.items():
+        Image.fromarray(v.numpy()).save(tmp_path / "in" / f"{k}.png")
+    s.inference(tmp_path / "in", tmp_path / "out", bs=1, noise_repeat=True)
+    for k, v in ims.items():
+        out = torch.from_numpy(np.asarray(Image.open(tmp_path / "out" / f"{k}.png")))
+        assert tuple(out.shape) == (v.shape[0] * 4, v.shape[1] * 4, 3)
+        lq = s.engine.u8_to_input(v[None].to(gpu))
+        exp = s.engine.output_to_u8(s.sample_tiled(lq, noise_repeat=True)).cpu()[0]
+        assert torch.equal(out, exp)
