@@ -378,11 +378,14 @@ extern "C" int rs_splitk_reduce_launch(const IGemmParams* pp, int out_dt, hipStr
 extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
     int BP, BC;
     pick_tile(M, Cout, BP, BC);
-    if (Cout > 64) BP = 128;  // igemm2 (128-pixel tiles) takes every single-source launch with more than 64 channels
+    if (Cout > 64) {          // igemm2 takes every single-source launch with more than 64 channels: ask it for its tile
+        int bp2 = 0, bc2 = 0;
+        if (rs_igemm2_pick(M, Cout, Ktot * (in_dt == RS_F16 ? 2 : 4), 1, &bp2, &bc2)) { BP = bp2 == 133 ? 64 : (bp2 == 256 || bp2 == 131) ? 256 : 128; BC = bc2; }
+    }
     const int tiles = ((M + BP - 1) / BP) * ((Cout + BC - 1) / BC);
     const int bk = in_dt == RS_F16 ? 64 : 32;
     const int nk = (Ktot + bk - 1) / bk;
-    if (tiles >= 200 || nk < 16 || (Cout & 3)) return 1;
+    if (tiles >= (BP == 64 ? 400 : 200) || nk < 16 || (Cout & 3)) return 1;
     // aim at ~3 workgroups per CU, keep >= 6 K stages per slice (RS_SPLITK_TARGET / RS_SPLITK_MINSTAGES override for tuning)
     static const int target = []() { const char* e = getenv("RS_SPLITK_TARGET"); return e ? atoi(e) : 512; }();
     static const int minst = []() { const char* e = getenv("RS_SPLITK_MINSTAGES"); return e ? atoi(e) : 8; }();

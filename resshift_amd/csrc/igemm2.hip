@@ -422,6 +422,15 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
             default: return launch2_cfg<TI, TO, 128, 128, 2, 4>(p, nz, st);
         }
     }
+    if (BP == 133) {
+        // small-M launches (16x16 / 8x8 UNet levels): 64-pixel tiles on 4 waves give twice the workgroups per split-K slice,
+        // i.e. half the fp32 partial-slab traffic for the same number of workgroups
+        switch (BC) {
+            case 160: return launch2_cfg<TI, TO, 64, 160, 2, 4>(p, nz, st);
+            case 192: return launch2_cfg<TI, TO, 64, 192, 2, 4>(p, nz, st);
+            default: return launch2_cfg<TI, TO, 64, 128, 2, 4>(p, nz, st);
+        }
+    }
     if (BP == 129) {
         // short-K GEMMs (K <= 4 stages: Swin qkv/proj/fc1, patch embeds): the launch is dominated by prologue + epilogue,
         // so use the 2-stage ring (<= 80 KB of LDS) that lets TWO workgroups share a CU and overlap each other
@@ -459,6 +468,9 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
     static const int var4 = []() { const char* e = getenv("RS_IGEMM_4WAVE"); return e ? atoi(e) : 0; }();
     static const int deep = []() { const char* e = getenv("RS_IGEMM_DEEP"); return e ? atoi(e) : 0; }();  // measured: no gain on the 8x8/16x16 levels (fixed launch cost dominates)
     if (tiles128 <= deep) *BP = 132;
+    // measured (profiles/r1_igemm_microbench_v6_smallm.txt): -16 % on the 16x16 / 8x8 level launches of one pass
+    static const int smallm = []() { const char* e = getenv("RS_IGEMM_SMALLM"); return e ? atoi(e) : 8192; }();
+    if (M <= smallm) *BP = 133;
     if (var4 == 1) *BP = 130;
     if (var4 == 16 && tiles128 >= 1024) *BP = 131;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;

@@ -38,6 +38,16 @@ SHAPES = [
     ("swin fc1 192->768 @32", 32, 192, 768, 1, 1, 1, 1, 0, 4 * U),
     ("swin emb 160->192 @64", 64, 160, 192, 1, 1, 1, 0, 0, 2 * U),
     ("unet skip 320->160 @64", 64, 320, 160, 1, 1, 1, 0, 0, 2 * U),
+    ("swin qkv 192->576 @16", 16, 192, 576, 1, 1, 1, 0, 0, 4 * U),
+    ("swin proj 192->192 @16", 16, 192, 192, 1, 1, 1, 0, 1, 4 * U),
+    ("swin fc1 192->768 @16", 16, 192, 768, 1, 1, 1, 1, 0, 4 * U),
+    ("swin fc2 768->192 @16", 16, 768, 192, 1, 1, 1, 0, 1, 4 * U),
+    ("swin qkv 192->576 @8", 8, 192, 576, 1, 1, 1, 0, 0, 6 * U),
+    ("swin proj 192->192 @8", 8, 192, 192, 1, 1, 1, 0, 1, 6 * U),
+    ("swin fc1 192->768 @8", 8, 192, 768, 1, 1, 1, 1, 0, 6 * U),
+    ("swin fc2 768->192 @8", 8, 768, 192, 1, 1, 1, 0, 1, 6 * U),
+    ("swin emb 640->192 @8", 8, 640, 192, 1, 1, 1, 0, 0, 3 * U),
+    ("swin unemb 192->640 @8", 8, 192, 640, 1, 1, 1, 0, 0, 3 * U),
     ("ae c3 512->512 @64", 64, 512, 512, 3, 1, 1, 0, 1, 17),
     ("ae c3 128->128 @256", 256, 128, 128, 3, 1, 1, 0, 1, 9),
     ("ae c3 256->256 @128", 128, 256, 256, 3, 1, 1, 0, 1, 8),
