@@ -163,11 +163,137 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
     else gn_apply_rows<T, RS_ACT_NONE>(p, ca, cb, b);
 }
 
+// Fused GroupNorm for small planes (HW <= 256: the 16x16 / 8x8 UNet levels): grid (C / SC, B), one workgroup owns a slice of
+// SC channels (whole groups, a multiple of 8 channels) of ONE image, keeps it in registers (<= MAXI 16-byte items per
+// thread), derives the group statistics through LDS and writes the normalised result - one launch and one read of x
+// instead of stats + apply.  Thread (pp, j) owns chunk j of the slice for pixels pp, pp+PP, ...
+template <typename T, int ACT, int MAXI>
+__device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (*red)[17], float* ca, float* cb) {
+    constexpr bool FAST = sizeof(T) == 2;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int cpg = p.C / p.groups;
+    const int nch = SC >> 3, PP = 256 / nch;
+    const int j = tid % nch, pp = tid / nch;
+    const int cs = blockIdx.x * SC;               // first channel of the slice
+    const bool active = pp < PP;
+    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + cs + j * 8;
+    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy + cs + j * 8;
+    Vec8<T> v[MAXI];
+    float sum[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int pix = pp + k * PP;
+        if (active && pix < p.HW) v[k].load(x + (long long)pix * p.ldx);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int pix = pp + k * PP;
+        if (active && pix < p.HW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = v[k].get(e); sum[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid][e] = sum[e]; red[tid][8 + e] = sq[e]; }
+    __syncthreads();
+    // fixed-order (deterministic) reduction in two short steps: per-channel column sums over the PP pixel lanes, then
+    // channels -> groups (a single thread per group walking PP x cpg entries would be a 500-deep dependent LDS chain)
+    if (tid < nch * 16) {
+        const int jj = tid >> 4, e16 = tid & 15;
+        float acc = 0.f;
+        for (int r = 0; r < PP; ++r) acc += red[r * nch + jj][e16];
+        cb[tid] = acc;                            // cb doubles as the column-sum scratch: [chunk][sum 0..7 | sq 0..7]
+    }
+    __syncthreads();
+    const int gps = SC / cpg;                     // groups in this slice
+    float gmean = 0.f, grstd = 0.f;
+    if (tid < gps) {
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += cb[(c >> 3) * 16 + (c & 7)];
+            q += cb[(c >> 3) * 16 + 8 + (c & 7)];
+        }
+        const float n = (float)cpg * (float)p.HW;
+        gmean = a / n;
+        const float var = fmaxf(q / n - gmean * gmean, 0.f);
+        grstd = 1.0f / sqrtf(var + p.eps);
+    }
+    __syncthreads();                              // column sums consumed: ca / cb now take the affine coefficients
+    if (tid < gps) {
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            float ga = p.gamma[cs + c] * grstd;
+            float be = p.beta[cs + c] - gmean * ga;
+            if (p.film) {
+                const float sc = 1.0f + p.film[cs + c];
+                ga *= sc;
+                be = fmaf(be, sc, p.film[p.C + cs + c]);
+            }
+            ca[c] = ga; cb[c] = be;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float a[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = ca[j * 8 + e]; c[e] = cb[j * 8 + e]; }
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int pix = pp + k * PP;
+        if (pix < p.HW) {
+            Vec8<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v[k].get(e), a[e], c[e])));
+            o.store(y + (long long)pix * p.ldy);
+        }
+    }
+}
+
+template <typename T, int MAXI>
+__global__ __launch_bounds__(256) void gn_fused_kernel(GNParams p, int SC) {
+    __shared__ float red[256][17];
+    __shared__ float ca[256], cb[512];
+    if (p.act == RS_ACT_SILU) gn_fused_body<T, RS_ACT_SILU, MAXI>(p, SC, red, ca, cb);
+    else if (p.act == RS_ACT_GELU) gn_fused_body<T, RS_ACT_GELU, MAXI>(p, SC, red, ca, cb);
+    else gn_fused_body<T, RS_ACT_NONE, MAXI>(p, SC, red, ca, cb);
+}
+
+// slice width for the fused kernel: whole groups, a multiple of 8 channels, >= 40 channels where possible (80-byte runs per
+// pixel), and narrow enough that the plane fits MAXI items per thread; 0 when no such width exists (two-kernel path)
+template <int MAXI> int gn_fused_slice(const GNParams& p) {
+    const int cpg = p.C / p.groups;
+    int g = 1;
+    while ((g * cpg) % 8) ++g;                       // g in {1,2,4,8}
+    if (g > p.groups || p.groups % g) return 0;
+    int best = 0;
+    for (int SC = g * cpg; SC <= 256 && SC <= p.C; SC *= 2) {
+        if (p.C % SC) break;
+        const int PP = 256 / (SC / 8);
+        if (PP < 1 || (p.HW + PP - 1) / PP > MAXI) break;
+        best = SC;
+        if (SC >= 40) break;
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, hipStream_t st) {
     const GNParams& p = *pp;
     if ((p.C % 8) || (p.C % p.groups) || p.C / 8 > 256 || p.groups > 256 || (p.ldx % 8) || (p.ldy % 8)) return -2;
+    // small planes: one fused launch (RS_GN_FUSED=0 keeps the two-kernel path for A/B runs)
+    static const bool fused_on = []() { const char* e = getenv("RS_GN_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused_on && p.HW <= 256) {
+        constexpr int MAXI = 12;
+        const int SC = gn_fused_slice<MAXI>(p);
+        if (SC > 0) {
+            dim3 g(p.C / SC, p.B);
+            if (dt == RS_F16) hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI>), g, dim3(256), 0, st, p, SC);
+            else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI>), g, dim3(256), 0, st, p, SC);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
     dim3 g1(p.S, p.B), g2(apply_slabs, p.B);
     const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
     if (dt == RS_F16) {

@@ -190,7 +190,8 @@ def test_conv_direct(gpu, in_dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 160), (1, 8, 8, 1280), (2, 32, 32, 192), (1, 64, 64, 128), (3, 8, 8, 960), (1, 16, 16, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 160), (1, 8, 8, 1280), (2, 32, 32, 192), (1, 64, 64, 128), (3, 8, 8, 960), (1, 16, 16, 64),
+                                   (2, 16, 16, 192), (2, 16, 16, 960), (2, 16, 16, 320), (2, 8, 8, 640), (1, 16, 12, 480)])  # planes <= 256 px: fused kernel
 @pytest.mark.parametrize("mode", ["plain", "silu", "film_silu"])
 def test_groupnorm(gpu, dtype, shape, mode):
     from resshift_amd import ops
