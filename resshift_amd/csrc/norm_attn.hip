@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
 // SC channels (whole groups, a multiple of 8 channels) of ONE image, keeps it in registers (<= MAXI 16-byte items per
 // thread), derives the group statistics through LDS and writes the normalised result - one launch and one read of x
 // instead of stats + apply.  Thread (pp, j) owns chunk j of the slice for pixels pp, pp+PP, ...
-template <typename T, int ACT, int MAXI>
+template <typename T, int ACT, int MAXI, int NT>
 __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (*red)[17], float* ca, float* cb) {
     constexpr bool FAST = sizeof(T) == 2;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups;
-    const int nch = SC >> 3, PP = 256 / nch;
+    const int nch = SC >> 3, PP = NT / nch;
     const int j = tid % nch, pp = tid / nch;
     const int cs = blockIdx.x * SC;               // first channel of the slice
     const bool active = pp < PP;
@@ -250,18 +250,18 @@ __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (
     }
 }
 
-template <typename T, int MAXI>
-__global__ __launch_bounds__(256) void gn_fused_kernel(GNParams p, int SC) {
-    __shared__ float red[256][17];
+template <typename T, int MAXI, int NT>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(GNParams p, int SC) {
+    __shared__ float red[NT][17];
     __shared__ float ca[256], cb[512];
-    if (p.act == RS_ACT_SILU) gn_fused_body<T, RS_ACT_SILU, MAXI>(p, SC, red, ca, cb);
-    else if (p.act == RS_ACT_GELU) gn_fused_body<T, RS_ACT_GELU, MAXI>(p, SC, red, ca, cb);
-    else gn_fused_body<T, RS_ACT_NONE, MAXI>(p, SC, red, ca, cb);
+    if (p.act == RS_ACT_SILU) gn_fused_body<T, RS_ACT_SILU, MAXI, NT>(p, SC, red, ca, cb);
+    else if (p.act == RS_ACT_GELU) gn_fused_body<T, RS_ACT_GELU, MAXI, NT>(p, SC, red, ca, cb);
+    else gn_fused_body<T, RS_ACT_NONE, MAXI, NT>(p, SC, red, ca, cb);
 }
 
 // slice width for the fused kernel: whole groups, a multiple of 8 channels, >= 40 channels where possible (80-byte runs per
 // pixel), and narrow enough that the plane fits MAXI items per thread; 0 when no such width exists (two-kernel path)
-template <int MAXI> int gn_fused_slice(const GNParams& p) {
+template <int MAXI, int NT> int gn_fused_slice(const GNParams& p) {
     const int cpg = p.C / p.groups;
     int g = 1;
     while ((g * cpg) % 8) ++g;                       // g in {1,2,4,8}
@@ -269,7 +269,7 @@ template <int MAXI> int gn_fused_slice(const GNParams& p) {
     int best = 0;
     for (int SC = g * cpg; SC <= 256 && SC <= p.C; SC *= 2) {
         if (p.C % SC) break;
-        const int PP = 256 / (SC / 8);
+        const int PP = NT / (SC / 8);
         if (PP < 1 || (p.HW + PP - 1) / PP > MAXI) break;
         best = SC;
         if (SC >= 40) break;
@@ -284,13 +284,24 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     if ((p.C % 8) || (p.C % p.groups) || p.C / 8 > 256 || p.groups > 256 || (p.ldx % 8) || (p.ldy % 8)) return -2;
     // small planes: one fused launch (RS_GN_FUSED=0 keeps the two-kernel path for A/B runs)
     static const bool fused_on = []() { const char* e = getenv("RS_GN_FUSED"); return !(e && e[0] == '0'); }();
+    // measured at B=32 (8-step bench, ms/step): fused up to 256 px 174.1, up to 1024 px 174.1, up to 4096 px 176.8 (too few,
+    // too fat workgroups at 64x64) -> the 1024-thread variant stays off by default
+    static const int fused_max = []() { const char* e = getenv("RS_GN_FUSED_MAXHW"); return e ? atoi(e) : 256; }();
     if (fused_on && p.HW <= 256) {
         constexpr int MAXI = 12;
-        const int SC = gn_fused_slice<MAXI>(p);
+        const int SC = gn_fused_slice<MAXI, 256>(p);
         if (SC > 0) {
             dim3 g(p.C / SC, p.B);
-            if (dt == RS_F16) hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI>), g, dim3(256), 0, st, p, SC);
-            else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI>), g, dim3(256), 0, st, p, SC);
+            if (dt == RS_F16) hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI, 256>), g, dim3(256), 0, st, p, SC);
+            else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI, 256>), g, dim3(256), 0, st, p, SC);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    } else if (fused_on && dt == RS_F16 && p.HW <= fused_max) {
+        // 32x32 / 64x64 planes in fp16: 1024 threads hold up to 20 items (80 VGPRs) each; the tensor is read once instead of twice
+        constexpr int MAXI = 20;
+        const int SC = gn_fused_slice<MAXI, 1024>(p);
+        if (SC > 0) {
+            hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI, 1024>), dim3(p.C / SC, p.B), dim3(1024), 0, st, p, SC);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
