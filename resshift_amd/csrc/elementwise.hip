@@ -56,21 +56,27 @@ __global__ void silu_kernel(const T* x, T* y, long long cnt) {
         y[g] = (T)rs_silu((float)x[g]);
 }
 
-// out[r][n] = bias[n] + sum_k act_in(x[r][k]) * w[n][k]   (tiny fp32 linears: time embedding / FiLM tables)
-__global__ void small_linear_kernel(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in,
-                                    int silu_out) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= R * N) return;
-    const int r = g / N, n = g - r * N;
+// out[r][n] = bias[n] + sum_k act_in(x[r][k]) * w[n][k]   (tiny fp32 linears: time embedding / FiLM tables).
+// One wavefront per output: lanes stride over K (coalesced weight reads), fixed-order butterfly reduction.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const float* w, const float* bias, float* y, int R, int K, int N,
+                                                           int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // output index, one per wave
+    if (g >= (long long)R * N) return;
+    const int r = (int)(g / N), n = (int)(g - (long long)r * N);
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
+    for (int k = lane; k < K; k += 64) {
         float xv = x[(long long)r * K + k];
         if (silu_in) xv = xv / (1.0f + expf(-xv));
         acc = fmaf(xv, w[(long long)n * K + k], acc);
     }
-    acc += bias ? bias[n] : 0.f;
-    if (silu_out) acc = acc / (1.0f + expf(-acc));
-    y[g] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        acc += bias ? bias[n] : 0.f;
+        if (silu_out) acc = acc / (1.0f + expf(-acc));
+        y[g] = acc;
+    }
 }
 
 // ---- bicubic ----------------------------------------------------------------
@@ -248,7 +254,7 @@ int rs_silu_launch(const void* x, void* y, int dt, long long cnt, hipStream_t st
 
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out,
                            hipStream_t st) {
-    hipLaunchKernelGGL(small_linear_kernel, dim3((R * N + 255) / 256), dim3(256), 0, st, x, w, bias, y, R, K, N, silu_in, silu_out);
+    hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)(((long long)R * N + 3) / 4)), dim3(256), 0, st, x, w, bias, y, R, K, N, silu_in, silu_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

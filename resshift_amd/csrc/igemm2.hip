@@ -30,8 +30,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <typename T, int FC, int FP> struct Stage2;
 template <int FC, int FP> struct Stage2<f16, FC, FP> {
     static __device__ __forceinline__ void run(const char* a0, const char* a1, const char* b0, const char* b1, f32x4 (&acc)[FC][FP]) {
+        // FC = 6 (BC = 192): both k-steps' fragments in flight would need > 128 VGPRs next to the epilogue state and spill
+        // inside the loop; a sched_barrier between the k-steps keeps one fragment set live at a time (these launches are the
+        // short-K, HBM-bound Swin GEMMs, where MFMA scheduling slack is irrelevant)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (FC >= 6 && ks == 1) __builtin_amdgcn_sched_barrier(0);
             const char* pa = ks ? a1 : a0;
             const char* pb = ks ? b1 : b0;
             f16x8 a[FC], b[FP];
@@ -271,19 +275,25 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
                     rv[i][j] = *(const f16x4*)((const f16*)res + mr + min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4));
             }
         }
+        // bias of every channel fragment up front as well (a load + wait per fragment inside the loop exposes its latency FC times)
+        f32x4 bvs[FC];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+            bvs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (quad) bvs[i] = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
+                else for (int r = 0; r < 4; ++r) bvs[i][r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
+            }
+        }
         auto finish = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    if (quad) bv = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
-                    else for (int r = 0; r < 4; ++r) bv[r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
-                }
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
-                    f32x4 v = acc[i][j] * p.out_scale + bv;
+                    f32x4 v = acc[i][j] * p.out_scale + bvs[i];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
                     if (res_fast) {
@@ -470,7 +480,7 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
     if (tiles128 <= deep) *BP = 132;
     // measured (profiles/r1_igemm_microbench_v6_smallm.txt): -16 % on the 16x16 / 8x8 level launches of one pass
     static const int smallm = []() { const char* e = getenv("RS_IGEMM_SMALLM"); return e ? atoi(e) : 8192; }();
-    if (M <= smallm) *BP = 133;
+    if (M <= smallm && tiles128 < 512) *BP = 133;   // (batched GEMMs with many small batches keep the 128-pixel tile)
     if (var4 == 1) *BP = 130;
     if (var4 == 16 && tiles128 >= 1024) *BP = 131;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;

@@ -219,19 +219,25 @@ __global__ __launch_bounds__(512, 2) void igemm3_kernel(IGemmParams p) {
                     rv[i][j] = *(const f16x4*)((const f16*)res + mr + min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4));
             }
         }
+        // bias of every channel fragment up front as well (a load + wait per fragment inside the loop exposes its latency FC times)
+        f32x4 bvs[FC];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+            bvs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (quad) bvs[i] = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
+                else for (int r = 0; r < 4; ++r) bvs[i][r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
+            }
+        }
         auto finish = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    if (quad) bv = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
-                    else for (int r = 0; r < 4; ++r) bv[r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
-                }
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
-                    f32x4 v = acc[i][j] * p.out_scale + bv;
+                    f32x4 v = acc[i][j] * p.out_scale + bvs[i];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
                     if (res_fast) {
