@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-end verification on the GPU box: tests, smoke, default bench, kernel trace and the two PMC traffic passes.
+# usage: scripts/final_check.sh <tag>   (outputs under gpurun_out/final_<tag>/)
+tag=${1:-r1}
+R=$(pwd); O=$R/gpurun_out/final_$tag; mkdir -p $O; export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-400 $O/bench.json
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o fp16 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass > $O/trace.log 2>&1)
+python scripts/rocpd_summary.py $(ls $O/trace/*.db | head -1) --top 16 > $O/kernel_trace.txt; head -24 $O/kernel_trace.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass > $O/pmc_$c.log 2>&1)
+done
+python scripts/collect_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic_igemm.json
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE   # raw CSVs are large; the JSON carries the per-launch figures
