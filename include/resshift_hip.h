@@ -146,7 +146,8 @@ long long rs_last_launch_count(rs_engine* e);
  * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[5] = {fp16-input igemm FLOPs,
  * fp32-input igemm FLOPs, summed igemm kernel milliseconds, igemm launch count, algorithmic HBM bytes (every
  * operand and result counted once)} of the last call (counts are always maintained; the time is 0 unless
- * profiling was on). */
+ * profiling was on).  The cost of an empty event pair, measured on the same stream, is subtracted from every
+ * bracket so that the sum is the kernels' own duration. */
 int rs_profile_enable(rs_engine* e, int on);
 int rs_profile_get(rs_engine* e, double* out5);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations

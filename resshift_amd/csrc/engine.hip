@@ -938,11 +938,23 @@ struct rs_engine {
         last_igemm_bytes = r.igemm_bytes;
         last_igemm_ms = 0.0;
         if (prof.on && prof.used) {
+            // The event pair itself costs stream time (two marker packets bracket every launch): measure that cost with
+            // empty pairs on the same stream and take it out, so that the per-launch figure is the kernel's own duration
+            // (checked against the rocprofv3 kernel trace of the same command).
+            constexpr int NCAL = 32;
+            hipEvent_t cal[2 * NCAL];
+            for (auto& ev : cal) (void)hipEventCreate(&ev);
+            for (int i = 0; i < NCAL; ++i) { (void)hipEventRecord(cal[2 * i], st); (void)hipEventRecord(cal[2 * i + 1], st); }
             (void)hipStreamSynchronize(st);
+            std::vector<float> empty(NCAL);
+            for (int i = 0; i < NCAL; ++i) { empty[i] = 0.f; (void)hipEventElapsedTime(&empty[i], cal[2 * i], cal[2 * i + 1]); }
+            for (auto& ev : cal) (void)hipEventDestroy(ev);
+            std::sort(empty.begin(), empty.end());
+            const float overhead = empty[NCAL / 2];   // median
             for (size_t i = 0; i + 1 < prof.used; i += 2) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
-                last_igemm_ms += ms;
+                last_igemm_ms += std::max(0.f, ms - overhead);
             }
         }
         if (r.err) return r.err;

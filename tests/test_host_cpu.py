@@ -202,3 +202,16 @@ def test_two_process_gloo_broadcast_and_sharding():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1] and res[0][2] and res[1][2]
     assert res[0][3][0] == 3 and res[1][3][0] == 2  # ceil(5/2) then the remainder
+
+
+def test_tile_origins_known_answers():
+    """ImageSpliterTh.extract_starts (utils/util_image.py:922-931) semantics, reference-free known answers; the product's
+    and the oracle's restatements must agree (both are also checked against the reference class when it is present)."""
+    from oracle import resshift_oracle as oc
+    from resshift_amd.tiling import extract_starts
+
+    cases = {(96, 64, 48): [0, 32], (130, 64, 64): [0, 64, 66], (200, 64, 50): [0, 50, 100, 136], (64, 64, 32): [0],
+             (100, 64, 20): [0, 20, 36], (63, 64, 64): [0], (128, 64, 64): [0, 64], (129, 64, 64): [0, 64, 65]}
+    for (length, pch, stride), exp in cases.items():
+        assert extract_starts(length, pch, stride) == exp
+        assert oc.tile_starts(length, pch, stride) == exp
