@@ -176,6 +176,10 @@ int rs_op_groupnorm(const void* x, void* y, const float* gamma_host, const float
                     int C, int groups, float eps, int act, int prec, void* stream);
 int rs_op_window_attention(const void* qkv, void* out, const float* bias_table_host /*[225][heads]*/, int B, int H, int W,
                            int heads, int shift, int prec, void* stream);
+/* fused Swin MLP, fp16 device tensors: y[M][E] = res + fc2(GELU(fc1(x))) with fc1 weights [HD][E], fc2 weights [E][HD]
+ * (row-major fp16, device), fp32 biases; res may be null (models/swin_transformer.py:17-33,279) */
+int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
+                   int M, int E, int HD, void* stream);
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream);
 int rs_op_vq(const float* z, const float* codebook_dev, float* zq, int32_t* idx, long long N, int NE, int D, void* stream);
 int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out_prec, void* stream);

@@ -40,6 +40,9 @@ int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C,
 int rs_nhwc_to_nchw_launch(const void* in, int in_dt, float* out, int B, int C, int HW, int ldi, int coff, hipStream_t st);
 int rs_axpbypcz_launch(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long cnt, hipStream_t st);
 int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st);
+int rs_swin_mlp_supported(int E, int HD);
+int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
+                       int ldres, int ldy, int E, int HD, hipStream_t st);
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
 int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int H, int W, int sf, int ldo, hipStream_t st);
 int rs_vq_launch(const float* z, const float* codebook, float* zq, int* idx, long long N, int NE, int D, hipStream_t st);
@@ -146,6 +149,25 @@ struct Exec {
             (void)hipEventRecord(e0, st);
         }
         check(rs_igemm_launch(&p, in_dt, out_dt, nz, st), what);
+        if (e1) (void)hipEventRecord(e1, st);
+    }
+    // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
+    void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
+                  int ldres, int ldy, int E, int HD) {
+        igemm_flops[0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
+        igemm_bytes += 2.0 * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
+        ++igemm_launches;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && prof->on) {
+            if (prof->used + 2 > prof->ev.size()) {
+                const size_t old = prof->ev.size();
+                prof->ev.resize(old + 1024);
+                for (size_t i = old; i < prof->ev.size(); ++i) (void)hipEventCreate(&prof->ev[i]);
+            }
+            e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
+            (void)hipEventRecord(e0, st);
+        }
+        check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, st), "swin_mlp");
         if (e1) (void)hipEventRecord(e1, st);
     }
 };
@@ -607,10 +629,21 @@ struct rs_engine {
             ex.tr(bp + "proj", e2);
             View n2 = ex.T(X.B, X.H, X.W, E, X.dt);
             gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE);
-            View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
-            conv1(ex, s.fc1, n2, f, nullptr, RS_ACT_GELU);
-            View e3 = ex.T(X.B, X.H, X.W, E, X.dt);
-            conv1(ex, s.fc2, f, e3, &e2);
+            View e3;
+            // fp16 storage: one fused launch, the [M][4E] hidden tensor never reaches HBM (swin_mlp.hip); RS_MLP_FUSED=0 or a
+            // small token count (RS_MLP_FUSED_MINM) keep the two GEMMs
+            static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 1; }();
+            static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 8192; }();
+            const int Mtok = X.B * X.H * X.W;
+            if (mlp_fused && X.dt == RS_F16 && rs_swin_mlp_supported(E, s.fc1.Cout) && s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.wh && s.fc2.wh) {
+                e3 = ex.T(X.B, X.H, X.W, E, X.dt);
+                if (!ex.dry) ex.swin_mlp(n2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout);
+            } else {
+                View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
+                conv1(ex, s.fc1, n2, f, nullptr, RS_ACT_GELU);
+                e3 = ex.T(X.B, X.H, X.W, E, X.dt);
+                conv1(ex, s.fc2, f, e3, &e2);
+            }
             ex.tr(bp + "out", e3);
             e = e3;
         }
@@ -1338,6 +1371,12 @@ int rs_op_window_attention(const void* qkv, void* out, const float* table_host, 
     return rc;
 }
 
+int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
+                   int M, int E, int HD, void* stream) {
+    const int rc = rs_swin_mlp_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, (hipStream_t)stream);
+    if (rc) fail("swin_mlp launch rejected the shape (fp16, E = 192, HD = 768 only)");
+    return rc;
+}
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream) {
     return rs_softmax_rows_launch(s, out, out_prec, nrows, ncols, ncols, ncols, (hipStream_t)stream);
 }

@@ -89,8 +89,14 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
     constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
     constexpr int CH = MfmaOps<TI>::CH;
     constexpr int BK = 8 * CH;                 // elements of K per stage (128 bytes per row)
-    constexpr int BCP = (BC + RND - 1) / RND * RND;   // weight rows rounded to whole load rounds
-    constexpr int RX = BP / RND, RW = BCP / RND;      // load rounds (one LDS-DMA instruction per thread per round)
+    // Weight rows per stage: the 2-stage ring only ever waits with vmcnt(0), so its last load round may be partial (only the
+    // waves that own rows < BC issue it: no zero rows DMA'd for BC = 160); the deeper rings count loads per wave and keep
+    // whole rounds (rows beyond BC are fetched as hardware zeros).
+    constexpr bool EXACT = (NS == 2);
+    constexpr int BCP = EXACT ? BC : (BC + RND - 1) / RND * RND;
+    constexpr int RWP = BC % RND;                     // rows of the partial round (a multiple of 8: one wave = 8 rows)
+    static_assert(RWP % 8 == 0, "partial round must be whole waves");
+    constexpr int RX = BP / RND, RW = (BC + RND - 1) / RND;   // load rounds (one LDS-DMA instruction per thread per round)
     constexpr int L = RX + RW;                 // LDS-DMA instructions per thread per stage
     constexpr int FP = BP / WPN / 16;          // wave tile = (BP/WPN) pixels x (BC/2) channels
     constexpr int FC = BC / 32;
@@ -192,8 +198,10 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
         const bool wk = kk < p.Ktot;
         const unsigned kb = (unsigned)kk * SZ;
 #pragma unroll
-        for (int i = 0; i < RW; ++i)
+        for (int i = 0; i < RW; ++i) {
+            if (EXACT && RWP && i == RW - 1 && wave >= RWP / 8) continue;   // wave-uniform: this wave's rows of the last round are >= BC
             lds_dma16(rw, sbase + (BP + RND * i) * 128, wk ? woff[i] + kb : INV);
+        }
         kk += BK;
         cc += BK;
         if (cc >= Ctot) {
@@ -215,19 +223,27 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
 #pragma unroll
         for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: fill NS-1 ring slots
+    // prologue: fill NS-1 ring slots - and, with only two slots, the second one as well: both are empty at this point, so
+    // stages 0 and 1 travel together and every workgroup saves one full load round trip (short-K launches have only 3)
     if (nk > 0) issue(0);
-    if (NS >= 3 && nk > 1) issue(1);
+    const bool pro2 = NS >= 3 || !(p.dbg & 64);   // (dbg 64: the 2-slot ring starts with one stage, for A/B timing)
+    if (nk > 1 && pro2) issue(1);
     if (NS >= 4 && nk > 2) issue(2);
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once at most the loads of the NS-2 later stages are still outstanding
-        {
+        // stage kt has landed once at most the loads of the later stages already issued are still outstanding
+        if (NS == 2) {
+            if (kt == 0 && nk > 1 && pro2) {   // stage 1 was issued with stage 0; its loads (one fewer on the waves that skip the partial round) may fly on
+                if (EXACT && RWP && wave >= RWP / 8) wait_vmcnt<L - 1>(); else wait_vmcnt<L>();
+            } else {
+                wait_vmcnt<0>();
+            }
+        } else {
             const int later = min(NS - 2, nk - 1 - kt);   // stages issued after kt that may still be in flight
             if (later >= 2) wait_vmcnt<2 * L>(); else if (later == 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
         }
         if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
         // refill the slot every wave finished reading before this barrier
-        if (kt + NS - 1 < nk && !(p.dbg & 1)) issue((kt + NS - 1) % NS);
+        if (kt + NS - 1 < nk && !(NS == 2 && kt == 0 && pro2) && !(p.dbg & 1)) issue((kt + NS - 1) % NS);
         const char* sb = smem + (kt % NS) * STAGE;
         if (!(p.dbg & 2)) Stage2<TI, FC, FP>::run(sb + la + swz0, sb + la + swz1, sb + lb + swz0, sb + lb + swz1, acc);
     }
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
 template <typename TI, typename TO, int BP, int BC, int NS, int NWV = 8>
 hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     constexpr int RND = 8 * NWV;
-    constexpr int BCP = (BC + RND - 1) / RND * RND;
+    constexpr int BCP = NS == 2 ? BC : (BC + RND - 1) / RND * RND;
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)NS * (BP + BCP) * 128;
     static_assert(NS * (BP + BCP) * 128 <= 160 * 1024, "LDS");
@@ -480,7 +496,8 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
     if (tiles128 <= deep) *BP = 132;
     // measured (profiles/r1_igemm_microbench_v6_smallm.txt): -16 % on the 16x16 / 8x8 level launches of one pass
     static const int smallm = []() { const char* e = getenv("RS_IGEMM_SMALLM"); return e ? atoi(e) : 8192; }();
-    if (M <= smallm && tiles128 < 512) *BP = 133;   // (batched GEMMs with many small batches keep the 128-pixel tile)
+    static const int force64 = []() { const char* e = getenv("RS_IGEMM_FORCE64"); return e ? atoi(e) : 0; }();   // A/B knob
+    if ((M <= smallm && tiles128 < 512) || force64) *BP = 133;   // (batched GEMMs with many small batches keep the 128-pixel tile)
     if (var4 == 1) *BP = 130;
     if (var4 == 16 && tiles128 >= 1024) *BP = 131;   // marker for the 128-pixel / 2-stage / 2-workgroups-per-CU variant
     return 1;

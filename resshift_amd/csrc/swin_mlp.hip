@@ -1,0 +1,204 @@
+// Fused Swin MLP for fp16 storage (models/swin_transformer.py:17-33 Mlp + the residual of :279):
+//     y = res + fc2( GELU( fc1(x) ) ),   x = GroupNorm'd tokens [M][E], fc1: E -> HD, fc2: HD -> E  (E = 192, HD = 768)
+// The two 1x1-conv GEMMs of this block are HBM-bound when run separately (profiles/r1_igemm_ablation.txt: the fc1 launch
+// spends 70 % of its time writing the [M][HD] hidden tensor, fc2 starts by reading it back: 2 x 201 MB at batch 32 on
+// the 64x64 level).  Here one workgroup owns 128 tokens: the token tile stays in LDS, the hidden activations exist only
+// as 64-wide chunks (MFMA accumulators -> bias + GELU -> fp16 -> LDS), and the fc2 accumulators stay in registers:
+//   for hc in 0 .. HD/64:   S  = X W1[hc]^T         (128 x 64, K = E)      24 MFMAs / wave
+//                           P  = fp16(GELU(S + b1))  -> LDS (16 KB)
+//                           O += P W2[:, hc]^T       (128 x E, K = 64)      24 MFMAs / wave
+// LDS (160 KB): X tile 48 KB | W1 chunk ring 2 x 24 KB | W2 chunk ring 2 x 24 KB | P 16 KB; weights arrive by LDS-DMA one
+// chunk ahead (they are L2-resident: every workgroup streams the same 590 KB).  Same LDS image / swizzle / MFMA operand
+// roles as igemm2.hip: weights are the A operand, tokens the B operand, so a lane ends with 4 consecutive output
+// channels of one token.
+#include "igemm_common.h"
+#include <type_traits>
+
+namespace {
+
+using namespace igemm_detail;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+struct MlpParams {
+    const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
+    int M, ldx, ldres, ldy;
+    unsigned x_bytes;
+};
+
+template <int E, int HD>
+__global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
+    constexpr int BP = 128, HC = 64, NHC = HD / HC, KS1 = E / 64;
+    constexpr int XS = 0, XS_STAGE = BP * 128;
+    constexpr int W1R = XS + KS1 * XS_STAGE, W1_STAGE = HC * 128, W1_SLOT = KS1 * W1_STAGE;
+    constexpr int W2R = W1R + 2 * W1_SLOT, W2_SLOT = E * 128;
+    constexpr int PS = W2R + 2 * W2_SLOT;
+    constexpr int FC2 = E / 32;                    // channel fragments per wave in GEMM2 (wave covers E/2 channels)
+    static_assert(E % 64 == 0 && HD % HC == 0 && PS + BP * 128 <= 160 * 1024, "shape");
+    static_assert(E % 64 == 0, "W2 rounds");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wp = wave & 3, wc = wave >> 2;             // 4 token-waves x 2 channel-waves
+    const int rr = 8 * wave + (lane >> 3);               // row inside a 64-row load round
+    const int kcp = (lane & 7) ^ ((lane >> 3) & 7);      // source K-chunk (swizzle on the source side)
+    const int m0 = blockIdx.x * BP;
+
+    constexpr unsigned INV = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(HD * E * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(HD * E * 2), 0x00020000);
+
+    // ---- token tile -> LDS (once)
+    {
+        char* base = smem + XS + (8 * wave) * 128;
+#pragma unroll
+        for (int i = 0; i < BP / 64; ++i) {
+            const int m = m0 + 64 * i + rr;
+            const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldx * 2u : INV;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) lds_dma16(rx, base + s * XS_STAGE + (64 * i) * 128, m < p.M ? ro + (unsigned)(s * 64 + kcp * 8) * 2u : INV);
+        }
+    }
+    // one hidden chunk of both weight matrices -> ring slot
+    auto issue_w = [&](int hc, int slot) {
+        char* b1 = smem + W1R + slot * W1_SLOT + (8 * wave) * 128;
+        const unsigned n = (unsigned)(hc * HC + rr);
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) lds_dma16(r1, b1 + s * W1_STAGE, (n * E + (unsigned)(s * 64 + kcp * 8)) * 2u);
+        char* b2 = smem + W2R + slot * W2_SLOT + (8 * wave) * 128;
+#pragma unroll
+        for (int i = 0; i < E / 64; ++i) lds_dma16(r2, b2 + (64 * i) * 128, ((unsigned)(64 * i + rr) * HD + (unsigned)(hc * HC + kcp * 8)) * 2u);
+    };
+    issue_w(0, 0);
+
+    const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};   // k-step 0 / 1 inside a 128-byte stage
+    f32x4 o[FC2][2];
+#pragma unroll
+    for (int i = 0; i < FC2; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int hc = 0; hc < NHC; ++hc) {
+        const int slot = hc & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk hc (and of the token tile) has landed
+        __builtin_amdgcn_s_barrier();                      // ... everybody's; GEMM2 of chunk hc-1 is finished everywhere
+        if (hc + 1 < NHC) issue_w(hc + 1, slot ^ 1);
+
+        // ---- GEMM1: S[h][m] over K = E, wave tile 32 hidden x 32 tokens
+        f32x4 s_[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { s_[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s_[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2 * KS1; ++ks) {
+            const int st = ks >> 1;
+            const char* pa = smem + W1R + slot * W1_SLOT + st * W1_STAGE + (wc * 32 + lr) * 128 + swz[ks & 1];
+            const char* pb = smem + XS + st * XS_STAGE + (wp * 32 + lr) * 128 + swz[ks & 1];
+            f16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = *(const f16x8*)(pa + i * 2048); b[i] = *(const f16x8*)(pb + i * 2048); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], s_[i][j], 0, 0, 0);
+        }
+        // ---- bias + GELU -> fp16 hidden chunk P[m][h] in LDS (a lane holds hidden h..h+3 of token m)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int h = wc * 32 + i * 16 + lg * 4;                                  // hidden index inside the chunk
+            const f32x4 bv = *(const f32x4*)(p.b1 + hc * HC + h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = wp * 32 + j * 16 + lr;
+                const f32x4 v = s_[i][j] + bv;
+                f16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (f16)rs_gelu_fast(v[r]);
+                *(f16x4*)(smem + PS + m * 128 + (((h >> 3) ^ (m & 7)) << 4) + (h & 7) * 2) = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's P stores are in LDS (a raw barrier carries no wait, and
+        __builtin_amdgcn_s_barrier();                        // __syncthreads() would also drain the weight prefetch in flight)
+        // ---- GEMM2: O[c][m] += W2[c][hc*64 ..] . P[m][..], wave tile (E/2) channels x 32 tokens, K = 64
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* pa = smem + W2R + slot * W2_SLOT + (wc * (E / 2) + lr) * 128 + swz[ks];
+            const char* pb = smem + PS + (wp * 32 + lr) * 128 + swz[ks];
+            f16x8 a[FC2], b[2];
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) a[i] = *(const f16x8*)(pa + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *(const f16x8*)(pb + j * 2048);
+#pragma unroll
+            for (int i = 0; i < FC2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], o[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
+
+    // ---- epilogue: + b2 + residual -> fp16 -> transposition through LDS -> 16-byte NHWC stores
+    constexpr int ROWB = (E / 2) * 2 + 16;
+    char* stg = smem + wave * 32 * ROWB;
+    const bool res_ok = p.res != nullptr;
+    f16x4 rv[FC2][2];
+    if (res_ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres;
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) rv[i][j] = *(const f16x4*)(p.res + mr + wc * (E / 2) + i * 16 + lg * 4);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FC2; ++i) {
+        const int n = wc * (E / 2) + i * 16 + lg * 4;
+        const f32x4 bv = *(const f32x4*)(p.b2 + n);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v = o[i][j] + bv;
+            if (res_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+            }
+            f16x4 hv;
+            hv[0] = (f16)v[0]; hv[1] = (f16)v[1]; hv[2] = (f16)v[2]; hv[3] = (f16)v[3];
+            *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = hv;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
+    for (int idx = lane; idx < NITEM; idx += 64) {
+        const int row = idx / CPR, c8 = idx - row * CPR;
+        const int m = m0 + wp * 32 + row;
+        if (m >= p.M) continue;
+        *(uint4*)(p.y + (long long)m * p.ldy + wc * (E / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+    }
+}
+
+}  // namespace
+
+// Launch conditions (checked by the caller as well): fp16 storage, E = 192, HD = 768, 16-byte aligned rows.
+extern "C" int rs_swin_mlp_supported(int E, int HD) { return E == 192 && HD == 768; }
+
+extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
+                                  int M, int ldx, int ldres, int ldy, int E, int HD, hipStream_t st) {
+    if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
+    const size_t xb = (size_t)M * ldx * 2;
+    if (xb >= 0xF0000000ull) return -2;
+    MlpParams p{};
+    p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.x_bytes = (unsigned)xb;
+    constexpr int LDS = 160 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)swin_mlp_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((swin_mlp_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -89,6 +89,20 @@ def window_attention(qkv, table, heads, shift):
     return out
 
 
+def swin_mlp(x, w1, b1, w2, b2, res=None):
+    """x: [M, E] fp16 device; w1 [HD, E], w2 [E, HD] (any float dtype, rounded to fp16 like the engine's weights)."""
+    lib = _lib.load()
+    M, E = x.shape
+    HD = w1.shape[0]
+    w1d, w2d = w1.to(x.device, torch.float16).contiguous(), w2.to(x.device, torch.float16).contiguous()
+    b1d, b2d = b1.to(x.device, torch.float32).contiguous(), b2.to(x.device, torch.float32).contiguous()
+    y = torch.empty(M, E, device=x.device, dtype=torch.float16)
+    rc = lib.rs_op_swin_mlp(x.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), res.data_ptr() if res is not None else None,
+                            y.data_ptr(), M, E, HD, _lib.current_stream_ptr())
+    _lib.check(rc, "swin_mlp")
+    return y
+
+
 def softmax_rows(s, out_prec=F32):
     lib = _lib.load()
     nrows, ncols = s.shape

@@ -32,6 +32,7 @@ SHAPES = [
     ("unet c3 640->640 @8", 8, 640, 640, 3, 1, 1, 0, 1, 10 * U),
     ("unet c3 1280->640 @8", 8, 1280, 640, 3, 1, 1, 0, 0, 2 * U),
     ("swin fc1 192->768 @64", 64, 192, 768, 1, 1, 1, 1, 0, 4 * U),
+    ("swin fc1-noact 192->768 @64", 64, 192, 768, 1, 1, 1, 0, 0, 0),   # ablation shape: fc1 without the GELU epilogue (count 0)
     ("swin fc2 768->192 @64", 64, 768, 192, 1, 1, 1, 0, 1, 4 * U),
     ("swin qkv 192->576 @64", 64, 192, 576, 1, 1, 1, 0, 0, 4 * U),
     ("swin proj 192->192 @64", 64, 192, 192, 1, 1, 1, 0, 1, 4 * U),

@@ -342,3 +342,25 @@ def test_layout_roundtrip(gpu):
     assert torch.equal(nhwc.cpu(), x.permute(0, 2, 3, 1).contiguous())
     back = ops.nhwc_to_nchw(nhwc)
     assert torch.equal(back.cpu(), x)
+
+
+@pytest.mark.parametrize("M,use_res", [(128 * 9, True), (1000, True), (64, False), (4096 * 3 + 37, True)])
+def test_swin_mlp_fused(gpu, M, use_res):
+    """swin_mlp.hip: res + fc2(GELU(fc1(x))) in one launch against torch fp32 on the same fp16-rounded operands; the only
+    extra rounding against the two-GEMM path is the fp16 hidden activation, which that path has as well."""
+    from resshift_amd import ops
+
+    E, HD = 192, 768
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, E, generator=g).to(gpu, torch.float16)
+    w1 = (torch.randn(HD, E, generator=g) / math.sqrt(E)).half()
+    w2 = (torch.randn(E, HD, generator=g) / math.sqrt(HD)).half()
+    b1, b2 = torch.randn(HD, generator=g) * 0.3, torch.randn(E, generator=g) * 0.3
+    res = torch.randn(M, E, generator=g).to(gpu, torch.float16) if use_res else None
+    y = ops.swin_mlp(x, w1, b1, w2, b2, res)
+    torch.cuda.synchronize()
+    h = F.gelu(x.float().cpu() @ w1.float().t() + b1).half().float()   # hidden activations are stored as fp16 in both paths
+    ref = h @ w2.float().t() + b2
+    if use_res:
+        ref = ref + res.float().cpu()
+    _close(y, ref, 2e-3, f"swin mlp M={M}")
