@@ -7,8 +7,8 @@
 //   for hc in 0 .. HD/64:   S  = X W1[hc]^T         (128 x 64, K = E)      24 MFMAs / wave
 //                           P  = fp16(GELU(S + b1))  -> LDS (16 KB)
 //                           O += P W2[:, hc]^T       (128 x E, K = 64)      24 MFMAs / wave
-// LDS (160 KB): X tile 48 KB | W1 chunk ring 2 x 24 KB | W2 chunk ring 2 x 24 KB | P 16 KB; weights arrive by LDS-DMA one
-// chunk ahead (they are L2-resident: every workgroup streams the same 590 KB).  Same LDS image / swizzle / MFMA operand
+// LDS (160 KB): W1 chunk ring 3 x 24 KB | W2 chunk ring 3 x 24 KB | P 16 KB; weights arrive by LDS-DMA two chunks ahead
+// (they are L2-resident: every workgroup streams the same 590 KB); the token fragments stay in registers.  Same LDS image / swizzle / MFMA operand
 // roles as igemm2.hip: weights are the A operand, tokens the B operand, so a lane ends with 4 consecutive output
 // channels of one token.
 #include "igemm_common.h"
@@ -27,19 +27,19 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
 struct MlpParams {
     const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
     int M, ldx, ldres, ldy;
-    unsigned x_bytes;
 };
 
 template <int E, int HD>
 __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
-    constexpr int BP = 128, HC = 64, NHC = HD / HC, KS1 = E / 64;
-    constexpr int XS = 0, XS_STAGE = BP * 128;
-    constexpr int W1R = XS + KS1 * XS_STAGE, W1_STAGE = HC * 128, W1_SLOT = KS1 * W1_STAGE;
-    constexpr int W2R = W1R + 2 * W1_SLOT, W2_SLOT = E * 128;
-    constexpr int PS = W2R + 2 * W2_SLOT;
+    constexpr int BP = 128, HC = 64, NHC = HD / HC, KS1 = E / 64, NSL = 3;
+    // LDS: W1 chunk ring | W2 chunk ring (NSL slots each, chunks travel two iterations ahead of their use) | P.  The token tile
+    // is NOT staged: its MFMA fragments are loop-invariant over the hidden chunks and live in registers (48 VGPRs).
+    constexpr int W1R = 0, W1_STAGE = HC * 128, W1_SLOT = KS1 * W1_STAGE;
+    constexpr int W2R = W1R + NSL * W1_SLOT, W2_SLOT = E * 128;
+    constexpr int PS = W2R + NSL * W2_SLOT;
     constexpr int FC2 = E / 32;                    // channel fragments per wave in GEMM2 (wave covers E/2 channels)
-    static_assert(E % 64 == 0 && HD % HC == 0 && PS + BP * 128 <= 160 * 1024, "shape");
-    static_assert(E % 64 == 0, "W2 rounds");
+    constexpr int LW = KS1 + E / 64;               // LDS-DMA instructions per thread per weight chunk
+    static_assert(E % 64 == 0 && HD % HC == 0 && NHC >= 3 && PS + BP * 128 <= 160 * 1024, "shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,22 +50,9 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     const int kcp = (lane & 7) ^ ((lane >> 3) & 7);      // source K-chunk (swizzle on the source side)
     const int m0 = blockIdx.x * BP;
 
-    constexpr unsigned INV = 0xF0000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(HD * E * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(HD * E * 2), 0x00020000);
 
-    // ---- token tile -> LDS (once)
-    {
-        char* base = smem + XS + (8 * wave) * 128;
-#pragma unroll
-        for (int i = 0; i < BP / 64; ++i) {
-            const int m = m0 + 64 * i + rr;
-            const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldx * 2u : INV;
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) lds_dma16(rx, base + s * XS_STAGE + (64 * i) * 128, m < p.M ? ro + (unsigned)(s * 64 + kcp * 8) * 2u : INV);
-        }
-    }
     // one hidden chunk of both weight matrices -> ring slot
     auto issue_w = [&](int hc, int slot) {
         char* b1 = smem + W1R + slot * W1_SLOT + (8 * wave) * 128;
@@ -77,17 +64,42 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         for (int i = 0; i < E / 64; ++i) lds_dma16(r2, b2 + (64 * i) * 128, ((unsigned)(64 * i + rr) * HD + (unsigned)(hc * HC + kcp * 8)) * 2u);
     };
     issue_w(0, 0);
+    issue_w(1, 1);
+
+    // token fragments (MFMA B operand: lane (lr, lg) holds 8 consecutive K values of token row lr): straight from global memory
+    f16x8 xf[2 * KS1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = min(m0 + wp * 32 + j * 16 + lr, p.M - 1);   // rows beyond M are clamped: their results are never stored
+        const f16* xr = p.x + (long long)m * p.ldx + lg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2 * KS1; ++ks) xf[ks][j] = *(const f16x8*)(xr + ks * 32);
+    }
+    // fc1 bias of the chunk being processed, fetched one chunk ahead
+    f32x4 bcur[2], bnxt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { bcur[i] = *(const f32x4*)(p.b1 + wc * 32 + i * 16 + lg * 4); bnxt[i] = bcur[i]; }
 
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};   // k-step 0 / 1 inside a 128-byte stage
     f32x4 o[FC2][2];
 #pragma unroll
     for (int i = 0; i < FC2; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    int slot = 0;
     for (int hc = 0; hc < NHC; ++hc) {
-        const int slot = hc & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk hc (and of the token tile) has landed
-        __builtin_amdgcn_s_barrier();                      // ... everybody's; GEMM2 of chunk hc-1 is finished everywhere
-        if (hc + 1 < NHC) issue_w(hc + 1, slot ^ 1);
+        // chunk hc has landed once only the younger loads may be outstanding: the bias pair and the LW DMA instructions of
+        // chunk hc+1 (issued one iteration ago, in that order); the tail iterations simply drain everything
+        if (hc + 1 < NHC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LW + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... everybody's part too; GEMM2 of chunk hc-1 is finished everywhere
+        if (hc + 2 < NHC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bnxt[i] = *(const f32x4*)(p.b1 + (hc + 1) * HC + wc * 32 + i * 16 + lg * 4);
+            issue_w(hc + 2, slot >= 1 ? slot - 1 : NSL - 1);   // == (slot + 2) % NSL: the slot chunk hc-1 just released
+        } else if (hc + 1 < NHC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bnxt[i] = *(const f32x4*)(p.b1 + (hc + 1) * HC + wc * 32 + i * 16 + lg * 4);
+        }
 
         // ---- GEMM1: S[h][m] over K = E, wave tile 32 hidden x 32 tokens
         f32x4 s_[2][2];
@@ -95,22 +107,20 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         for (int i = 0; i < 2; ++i) { s_[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s_[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 2 * KS1; ++ks) {
-            const int st = ks >> 1;
-            const char* pa = smem + W1R + slot * W1_SLOT + st * W1_STAGE + (wc * 32 + lr) * 128 + swz[ks & 1];
-            const char* pb = smem + XS + st * XS_STAGE + (wp * 32 + lr) * 128 + swz[ks & 1];
-            f16x8 a[2], b[2];
+            const char* pa = smem + W1R + slot * W1_SLOT + (ks >> 1) * W1_STAGE + (wc * 32 + lr) * 128 + swz[ks & 1];
+            f16x8 a[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = *(const f16x8*)(pa + i * 2048); b[i] = *(const f16x8*)(pb + i * 2048); }
+            for (int i = 0; i < 2; ++i) a[i] = *(const f16x8*)(pa + i * 2048);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) s_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], s_[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) s_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], xf[ks][j], s_[i][j], 0, 0, 0);
         }
         // ---- bias + GELU -> fp16 hidden chunk P[m][h] in LDS (a lane holds hidden h..h+3 of token m)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int h = wc * 32 + i * 16 + lg * 4;                                  // hidden index inside the chunk
-            const f32x4 bv = *(const f32x4*)(p.b1 + hc * HC + h);
+            const f32x4 bv = bcur[i];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int m = wp * 32 + j * 16 + lr;
@@ -138,6 +148,8 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], o[i][j], 0, 0, 0);
         }
+        bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
+        slot = slot + 1 == NSL ? 0 : slot + 1;
     }
     __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
 
@@ -188,11 +200,9 @@ extern "C" int rs_swin_mlp_supported(int E, int HD) { return E == 192 && HD == 7
 extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
                                   int M, int ldx, int ldres, int ldy, int E, int HD, hipStream_t st) {
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
-    const size_t xb = (size_t)M * ldx * 2;
-    if (xb >= 0xF0000000ull) return -2;
     MlpParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
-    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.x_bytes = (unsigned)xb;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy;
     constexpr int LDS = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
