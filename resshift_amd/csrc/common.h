@@ -129,4 +129,9 @@ struct WinAttnParams {
     const float* bias_n;  // [heads][64 (query i)][64 (key j)] (MFMA kernel); may be null -> VALU kernel is used
     int B, H, W, heads, shift, ldq, ldo;
     float scale;
+    // fused qkv projection (win_attn_qkv_kernel): normalised tokens instead of a qkv tensor
+    const void* x;        // [B,H,W,ldx] fp16, features 0..E-1
+    const void* wqkv;     // [3E][E] fp16 row-major (swin_transformer.py:85 qkv Linear)
+    const float* bqkv;    // [3E]
+    int ldx;
 };

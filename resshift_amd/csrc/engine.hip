@@ -40,6 +40,8 @@ int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C,
 int rs_nhwc_to_nchw_launch(const void* in, int in_dt, float* out, int B, int C, int HW, int ldi, int coff, hipStream_t st);
 int rs_axpbypcz_launch(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long cnt, hipStream_t st);
 int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st);
+int rs_win_attn_qkv_supported(int heads, int E);
+int rs_win_attn_qkv_launch(const WinAttnParams* p, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                        int ldres, int ldy, int E, int HD, hipStream_t st);
@@ -149,6 +151,25 @@ struct Exec {
             (void)hipEventRecord(e0, st);
         }
         check(rs_igemm_launch(&p, in_dt, out_dt, nz, st), what);
+        if (e1) (void)hipEventRecord(e1, st);
+    }
+    // fused qkv projection + window attention: the projection's FLOPs / compulsory bytes stay in the MFMA-family bookkeeping
+    void win_attn_qkv(const WinAttnParams& p, int E) {
+        const double M = (double)p.B * p.H * p.W;
+        igemm_flops[0] += 2.0 * M * 3.0 * E * E;
+        igemm_bytes += 2.0 * (M * E * 2.0 + 3.0 * E * E);
+        ++igemm_launches;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && prof->on) {
+            if (prof->used + 2 > prof->ev.size()) {
+                const size_t old = prof->ev.size();
+                prof->ev.resize(old + 1024);
+                for (size_t i = old; i < prof->ev.size(); ++i) (void)hipEventCreate(&prof->ev[i]);
+            }
+            e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
+            (void)hipEventRecord(e0, st);
+        }
+        check(rs_win_attn_qkv_launch(&p, st), "win_attn_qkv");
         if (e1) (void)hipEventRecord(e1, st);
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
@@ -613,11 +634,26 @@ struct rs_engine {
             const std::string bp = "blk" + std::to_string(bi++) + ".";
             View n = ex.T(X.B, X.H, X.W, E, X.dt);
             gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE);
-            View qkv = ex.T(X.B, X.H, X.W, 3 * E, X.dt);
-            conv1(ex, s.qkv, n, qkv);
-            ex.tr(bp + "qkv", qkv);
+            // fp16 storage: qkv projection fused into the attention kernel (the [M][3E] tensor never reaches HBM); RS_ATTN_FUSED=0
+            // and the debug trace (which records qkv) keep the two launches
+            static const int attn_fused = []() { const char* v = getenv("RS_ATTN_FUSED"); return v ? atoi(v) : 1; }();
+            const bool fuse_qkv = attn_fused && X.dt == RS_F16 && rs_win_attn_qkv_supported(heads, E) && s.bias_n && s.qkv.wh && !ex.trace;
+            View qkv;
+            if (!fuse_qkv) {
+                qkv = ex.T(X.B, X.H, X.W, 3 * E, X.dt);
+                conv1(ex, s.qkv, n, qkv);
+                ex.tr(bp + "qkv", qkv);
+            }
             View a = ex.T(X.B, X.H, X.W, E, X.dt);
-            if (!ex.dry) {
+            if (fuse_qkv) {
+                if (!ex.dry) {
+                    WinAttnParams p{};
+                    p.out = a.p; p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift; p.ldo = a.ld;
+                    p.scale = 1.0f / std::sqrt((float)(E / heads));
+                    p.x = n.p; p.ldx = n.ld; p.wqkv = s.qkv.wh; p.bqkv = s.qkv.bias;
+                    ex.win_attn_qkv(p, E);
+                }
+            } else if (!ex.dry) {
                 WinAttnParams p{};
                 p.qkv = qkv.p; p.out = a.p; p.bias_t = s.bias_t; p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads;
                 p.shift = s.shift; p.ldq = qkv.ld; p.ldo = a.ld; p.scale = 1.0f / std::sqrt((float)(E / heads));
@@ -1367,6 +1403,27 @@ int rs_op_window_attention(const void* qkv, void* out, const float* table_host, 
     if (rc) fail("window attention launch rejected the shape");
     (void)hipStreamSynchronize(st);
     (void)hipFree(d);
+    (void)hipFree(dn);
+    return rc;
+}
+
+int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, void* out, const float* table_host, int B, int H, int W,
+                               int heads, int shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> bn((size_t)heads * 64 * 64);
+    for (int h = 0; h < heads; ++h)
+        for (int i = 0; i < 64; ++i)
+            for (int j = 0; j < 64; ++j) {
+                const int idx = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+                bn[((size_t)h * 64 + i) * 64 + j] = table_host[(size_t)idx * heads + h];
+            }
+    float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
+    WinAttnParams p{};
+    p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
+    p.x = x; p.wqkv = wqkv_dev; p.bqkv = bqkv_dev; p.ldx = heads * 32;
+    const int rc = rs_win_attn_qkv_launch(&p, st);
+    if (rc) fail("fused qkv + window attention launch rejected the shape (fp16, 6 heads of 32 only)");
+    (void)hipStreamSynchronize(st);
     (void)hipFree(dn);
     return rc;
 }

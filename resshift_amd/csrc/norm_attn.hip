@@ -556,6 +556,199 @@ __global__ __launch_bounds__(512) void win_attn_mfma_kernel(WinAttnParams p) {
 
 }  // namespace
 
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr3_t;
+__device__ __forceinline__ void lds_dma16_na(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr3_t)lds, 16, voff, 0, 0, 0);
+}
+
+// Window attention with the qkv projection fused in (fp16 storage, E = 32 * heads <= 192, heads = 6 in every shipped config):
+// one workgroup per window, one wave per head.  The window's 64 normalised tokens are gathered (roll + partition folded
+// into the addressing) into LDS once; wave h multiplies them with ITS 96 rows of the qkv weight (q_h, k_h, v_h: no other
+// wave needs them, so they come straight from L2 into registers in MFMA A-operand layout) - 144 MFMAs - and the
+// accumulators ARE the attention operands: a lane ends with 8 head-dim values of one token for q and for k, the same 8 for
+// both, which is all S^T = K Q^T needs (the contraction index may be permuted consistently).  V goes through the same LDS
+// transposition as in win_attn_mfma_kernel, everything after that is identical.  The [M][3E] qkv tensor (151 MB at batch 32
+// on the 64x64 level) never exists.
+__global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsigned x_bytes) {
+    constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
+    constexpr int XS_STAGE = NT * 128;                       // 64 token rows x 128 B per 64-wide K stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    f16* vt = (f16*)(smem + 3 * XS_STAGE) + (size_t)h * HD * VP;   // [HD][VP] of this head
+    const int nwx = p.W / WS;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    const int b = blockIdx.y;
+    auto pixel = [&](int t) -> long long {
+        int sy = wy * WS + (t >> 3) + p.shift; if (sy >= p.H) sy -= p.H;
+        int sx = wx * WS + (t & 7) + p.shift; if (sx >= p.W) sx -= p.W;
+        return ((long long)b * p.H + sy) * p.W + sx;
+    };
+    // ---- tokens of the window -> LDS: 8 row groups x 3 K stages = 24 LDS-DMA instructions, 4 per wave
+    {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+        const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = h * 4 + q, st = it >> 3, grp = it & 7;
+            const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldx + st * 64 + kcp * 8) * 2u;
+            lds_dma16_na(rx, smem + st * XS_STAGE + (grp * 8) * 128, off);
+        }
+    }
+    long long pix[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) pix[f] = pixel(16 * f + lr);
+    const f16* wq = (const f16*)p.wqkv;
+    const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
+    // one projection pass: this head's 32 output features starting at weight row n0 -> acc[2 feature frags][4 token frags]
+    auto project = [&](int n0, f32x4 (&acc)[2][4]) {
+        f16x8 wf[2][KS];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[f][ks] = *(const f16x8*)(wq + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const f32x4 bv = *(const f32x4*)(p.bqkv + n0 + 16 * f + 4 * lg);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[f][fi] = bv;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 xb[4];
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) xb[fi] = *(const f16x8*)(smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1]);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f][ks], xb[fi], acc[f][fi], 0, 0, 0);
+        }
+    };
+    auto pack = [&](const f32x4 (&acc)[2][4], f16x8 (&out)[4]) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const f32x4 a = acc[0][fi], c = acc[1][fi];
+            out[fi] = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // the window's tokens are in LDS
+    f16x8 kf[4], qf[4];
+    {
+        f32x4 acc[2][4];
+        project(h * HD, acc);            // q_h: lane (lr,lg) holds d = {4lg+r, 16+4lg+r} of token 16fi+lr
+        pack(acc, qf);
+        project(E + h * HD, acc);        // k_h: the same d set per lane -> a consistent contraction order for S^T
+        pack(acc, kf);
+        project(2 * E + h * HD, acc);    // v_h -> V^T[d][token] in LDS
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vt[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = (f16)acc[f][ft][r];
+    }
+    f32x4 s[4][4];  // [fj][fi]
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+            s[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[fj], qf[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+    if (p.shift > 0) {
+        auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
+        rid_i = band(lr & 7);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
+    }
+    float inv[4];
+    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+        const int i = 16 * fi + lr;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
+                s[fj][fi][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[fj][fi][r] - m);
+                s[fj][fi][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[fi] = 1.0f / l;
+    }
+    __syncthreads();  // V^T of every head is in LDS (only this head's is read, but the barrier also orders the ds_writes)
+    f32x4 o[2][4];    // [fd][fi]
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 va[2], pb[4];
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            const f16* row = vt + (16 * fd + lr) * VP + 32 * ks + 4 * lg;
+            const f16x4 lo = *(const f16x4*)row, hi = *(const f16x4*)(row + 16);
+            va[fd] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const f32x4 a = s[2 * ks][fi], c = s[2 * ks + 1][fi];
+            pb[fi] = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+        }
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
+    }
+    f16* out = (f16*)p.out;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            f16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
+            *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+        }
+}
+
+}  // namespace
+
+// fused qkv projection + window attention (fp16, 6 heads of 32): x, wqkv, bqkv, ldx of the parameter block are used, qkv is not
+extern "C" int rs_win_attn_qkv_supported(int heads, int E) { return heads == 6 && E == 192; }
+extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
+    const WinAttnParams& p = *pp;
+    if ((p.H % 8) || (p.W % 8) || !rs_win_attn_qkv_supported(p.heads, 32 * p.heads) || (p.ldx % 8) || (p.ldo % 8) || !p.bias_n) return -2;
+    if (p.shift != 0 && p.shift != 4) return -2;
+    const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 2;
+    if (xb >= 0xF0000000ull) return -2;
+    const size_t lds = 3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16);
+    hipLaunchKernelGGL(win_attn_qkv_kernel, dim3((p.H / 8) * (p.W / 8), p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int rs_win_attn_launch(const WinAttnParams* pp, int dt, hipStream_t st) {
     const WinAttnParams& p = *pp;
     if ((p.H % 8) || (p.W % 8) || p.heads < 1 || p.heads > 8 || (p.ldq % 8) || (p.ldo % 8)) return -2;

@@ -89,6 +89,19 @@ def window_attention(qkv, table, heads, shift):
     return out
 
 
+def window_attention_qkv(x, wqkv, bqkv, table, heads, shift):
+    """x: [B,H,W,E] fp16 normalised tokens; wqkv [3E,E], bqkv [3E]; fused projection + attention; returns [B,H,W,E]."""
+    lib = _lib.load()
+    B, H, W, E = x.shape
+    wd = wqkv.to(x.device, torch.float16).contiguous()
+    bd = bqkv.to(x.device, torch.float32).contiguous()
+    out = torch.empty(B, H, W, E, device=x.device, dtype=torch.float16)
+    th, tp = _hostf(table)
+    rc = lib.rs_op_window_attention_qkv(x.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), tp, B, H, W, heads, shift, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_window_attention_qkv")
+    return out
+
+
 def swin_mlp(x, w1, b1, w2, b2, res=None):
     """x: [M, E] fp16 device; w1 [HD, E], w2 [E, HD] (any float dtype, rounded to fp16 like the engine's weights)."""
     lib = _lib.load()

@@ -364,3 +364,25 @@ def test_swin_mlp_fused(gpu, M, use_res):
     if use_res:
         ref = ref + res.float().cpu()
     _close(y, ref, 2e-3, f"swin mlp M={M}")
+
+
+@pytest.mark.parametrize("hw,shift", [((16, 16), 0), ((16, 16), 4), ((8, 8), 0), ((24, 16), 4), ((64, 64), 4)])
+def test_window_attention_fused_qkv(gpu, hw, shift):
+    """win_attn_qkv_kernel: qkv Linear (swin_transformer.py:85,121) + window attention in one launch, against the torch
+    reference fed with the SAME projection (weights rounded to fp16, qkv itself rounded to fp16 as the kernel's operands are)."""
+    from resshift_amd import ops
+
+    H, W = hw
+    heads, E = 6, 192
+    g = torch.Generator().manual_seed(H * 11 + shift)
+    x = torch.randn(2, E, H, W, generator=g)
+    wqkv = (torch.randn(3 * E, E, generator=g) / math.sqrt(E)).half()
+    bqkv = torch.randn(3 * E, generator=g) * 0.2
+    table = torch.randn(225, heads, generator=g) * 0.5
+    xd = _nhwc(x, torch.float16, gpu)
+    xr = _ref_in(xd)                                                        # [2, E, H, W] fp32 of the fp16 tokens
+    qkv = torch.einsum("bchw,oc->bohw", xr, wqkv.float()) + bqkv[None, :, None, None]
+    ref = _window_attention_reference(qkv.half().float(), table, heads, shift)
+    out = ops.window_attention_qkv(xd, wqkv, bqkv, table, heads, shift)
+    torch.cuda.synchronize()
+    _close(out.permute(0, 3, 1, 2), ref, 3e-3, f"fused qkv window attention {hw} shift {shift}")
