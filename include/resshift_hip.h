@@ -177,9 +177,10 @@ int rs_op_groupnorm(const void* x, void* y, const float* gamma_host, const float
 int rs_op_window_attention(const void* qkv, void* out, const float* bias_table_host /*[225][heads]*/, int B, int H, int W,
                            int heads, int shift, int prec, void* stream);
 /* fused qkv projection + window attention (fp16, 6 heads of 32): x [B,H,W,192] normalised tokens, wqkv [576][192] fp16 device,
- * bqkv [576] fp32 device, table as in rs_op_window_attention (host); out [B,H,W,192] */
-int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, void* out, const float* table_host, int B, int H, int W,
-                               int heads, int shift, void* stream);
+ * bqkv [576] fp32 device, table as in rs_op_window_attention (host); out [B,H,W,192].  With wproj_dev ([192][192] fp16) and
+ * bproj_dev the output projection is fused as well and `res` (fp16 [B,H,W,192], may be null) is added: out = res + proj(attn) */
+int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, const void* wproj_dev, const float* bproj_dev,
+                               const void* res, void* out, const float* table_host, int B, int H, int W, int heads, int shift, void* stream);
 /* fused Swin MLP, fp16 device tensors: y[M][E] = res + fc2(GELU(fc1(x))) with fc1 weights [HD][E], fc2 weights [E][HD]
  * (row-major fp16, device), fp32 biases; res may be null (models/swin_transformer.py:17-33,279) */
 int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,

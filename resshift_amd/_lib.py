@@ -100,7 +100,7 @@ SIGNATURES = {
     "rs_op_gemm_nt": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "rs_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "rs_op_window_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "rs_op_window_attention_qkv": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rs_op_window_attention_qkv": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rs_op_swin_mlp": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rs_op_softmax_rows": (_I, [_P, _P, _LL, _I, _I, _P]),
     "rs_op_vq": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),

@@ -134,4 +134,9 @@ struct WinAttnParams {
     const void* wqkv;     // [3E][E] fp16 row-major (swin_transformer.py:85 qkv Linear)
     const float* bqkv;    // [3E]
     int ldx;
+    // optional fused output projection + residual (swin_transformer.py:141-143,277): out = res + proj(attention)
+    const void* wproj;    // [E][E] fp16 row-major, null -> `out` receives the attention result itself
+    const float* bproj;   // [E]
+    const void* res;      // [B,H,W,ldres] fp16 shortcut, read at the same (un-shifted) pixels the result is written to
+    int ldres;
 };

@@ -156,8 +156,8 @@ struct Exec {
     // fused qkv projection + window attention: the projection's FLOPs / compulsory bytes stay in the MFMA-family bookkeeping
     void win_attn_qkv(const WinAttnParams& p, int E) {
         const double M = (double)p.B * p.H * p.W;
-        igemm_flops[0] += 2.0 * M * 3.0 * E * E;
-        igemm_bytes += 2.0 * (M * E * 2.0 + 3.0 * E * E);
+        igemm_flops[0] += 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E;
+        igemm_bytes += 2.0 * (M * E * (p.res ? 3.0 : 2.0) + (p.wproj ? 4.0 : 3.0) * E * E);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && prof->on) {
@@ -636,7 +636,7 @@ struct rs_engine {
             gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE);
             // fp16 storage: qkv projection fused into the attention kernel (the [M][3E] tensor never reaches HBM); RS_ATTN_FUSED=0
             // and the debug trace (which records qkv) keep the two launches
-            static const int attn_fused = []() { const char* v = getenv("RS_ATTN_FUSED"); return v ? atoi(v) : 1; }();
+            static const int attn_fused = []() { const char* v = getenv("RS_ATTN_FUSED"); return v ? atoi(v) : 2; }();
             const bool fuse_qkv = attn_fused && X.dt == RS_F16 && rs_win_attn_qkv_supported(heads, E) && s.bias_n && s.qkv.wh && !ex.trace;
             View qkv;
             if (!fuse_qkv) {
@@ -644,13 +644,17 @@ struct rs_engine {
                 conv1(ex, s.qkv, n, qkv);
                 ex.tr(bp + "qkv", qkv);
             }
-            View a = ex.T(X.B, X.H, X.W, E, X.dt);
+            const bool fuse_proj = fuse_qkv && attn_fused >= 2 && s.proj.wh;   // ... and the output projection + shortcut as well
+            View a, e2;
+            if (fuse_proj) e2 = ex.T(X.B, X.H, X.W, E, X.dt); else a = ex.T(X.B, X.H, X.W, E, X.dt);
             if (fuse_qkv) {
                 if (!ex.dry) {
                     WinAttnParams p{};
-                    p.out = a.p; p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift; p.ldo = a.ld;
+                    p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
                     p.scale = 1.0f / std::sqrt((float)(E / heads));
                     p.x = n.p; p.ldx = n.ld; p.wqkv = s.qkv.wh; p.bqkv = s.qkv.bias;
+                    if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.wh; p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld; }
+                    else { p.out = a.p; p.ldo = a.ld; }
                     ex.win_attn_qkv(p, E);
                 }
             } else if (!ex.dry) {
@@ -659,9 +663,11 @@ struct rs_engine {
                 p.shift = s.shift; p.ldq = qkv.ld; p.ldo = a.ld; p.scale = 1.0f / std::sqrt((float)(E / heads));
                 ex.check(rs_win_attn_launch(&p, X.dt, ex.st), "win_attn");
             }
-            ex.tr(bp + "attn", a);
-            View e2 = ex.T(X.B, X.H, X.W, E, X.dt);
-            conv1(ex, s.proj, a, e2, &e);
+            if (!fuse_proj) {
+                ex.tr(bp + "attn", a);
+                e2 = ex.T(X.B, X.H, X.W, E, X.dt);
+                conv1(ex, s.proj, a, e2, &e);
+            }
             ex.tr(bp + "proj", e2);
             View n2 = ex.T(X.B, X.H, X.W, E, X.dt);
             gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE);
@@ -1407,8 +1413,8 @@ int rs_op_window_attention(const void* qkv, void* out, const float* table_host, 
     return rc;
 }
 
-int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, void* out, const float* table_host, int B, int H, int W,
-                               int heads, int shift, void* stream) {
+int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, const void* wproj_dev, const float* bproj_dev,
+                               const void* res, void* out, const float* table_host, int B, int H, int W, int heads, int shift, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     std::vector<float> bn((size_t)heads * 64 * 64);
     for (int h = 0; h < heads; ++h)
@@ -1421,6 +1427,7 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
     WinAttnParams p{};
     p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
     p.x = x; p.wqkv = wqkv_dev; p.bqkv = bqkv_dev; p.ldx = heads * 32;
+    p.wproj = wproj_dev; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
     const int rc = rs_win_attn_qkv_launch(&p, st);
     if (rc) fail("fused qkv + window attention launch rejected the shape (fp16, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);

@@ -723,6 +723,21 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
             for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
     }
     f16* out = (f16*)p.out;
+    if (!p.wproj) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int fd = 0; fd < 2; ++fd) {
+                f16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
+                *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+            }
+        return;
+    }
+    // ---- fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format), then
+    // wave h produces output features 32h .. 32h+31 for all 64 tokens: 48 MFMAs, weights straight from L2 like the qkv passes
+    __syncthreads();   // every wave is done with the token tile (projection passes) before it is overwritten
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -730,7 +745,49 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
             f16x4 hv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
-            *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+            const int t = 16 * fi + lr, c = h * HD + 16 * fd + 4 * lg;     // token row, feature
+            *(f16x4*)(smem + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2) = hv;
+        }
+    const f16* wp = (const f16*)p.wproj;
+    f16x8 wf2[2][KS];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf2[f][ks] = *(const f16x8*)(wp + (long long)(h * HD + 16 * f + lr) * E + ks * 32 + lg * 8);
+    f32x4 acc2[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const f32x4 bv = *(const f32x4*)(p.bproj + h * HD + 16 * f + 4 * lg);
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) acc2[f][fi] = bv;
+    }
+    f16x4 rv[2][4];
+    const f16* res = (const f16*)p.res;
+    if (res) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) rv[f][fi] = *(const f16x4*)(res + pix[fi] * p.ldres + h * HD + 16 * f + 4 * lg);
+    }
+    __syncthreads();   // all heads' attention results are in LDS
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        f16x8 xb[4];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) xb[fi] = *(const f16x8*)(smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc2[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[f][ks], xb[fi], acc2[f][fi], 0, 0, 0);
+    }
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
+            *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * f + 4 * lg) = hv;
         }
 }
 
@@ -742,6 +799,7 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     const WinAttnParams& p = *pp;
     if ((p.H % 8) || (p.W % 8) || !rs_win_attn_qkv_supported(p.heads, 32 * p.heads) || (p.ldx % 8) || (p.ldo % 8) || !p.bias_n) return -2;
     if (p.shift != 0 && p.shift != 4) return -2;
+    if (p.wproj && (!p.bproj || (p.res && (p.ldres % 4)))) return -2;
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 2;
     if (xb >= 0xF0000000ull) return -2;
     const size_t lds = 3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16);

@@ -89,15 +89,20 @@ def window_attention(qkv, table, heads, shift):
     return out
 
 
-def window_attention_qkv(x, wqkv, bqkv, table, heads, shift):
-    """x: [B,H,W,E] fp16 normalised tokens; wqkv [3E,E], bqkv [3E]; fused projection + attention; returns [B,H,W,E]."""
+def window_attention_qkv(x, wqkv, bqkv, table, heads, shift, wproj=None, bproj=None, res=None):
+    """x: [B,H,W,E] fp16 normalised tokens; wqkv [3E,E], bqkv [3E]; fused projection + attention (+ output projection wproj
+    [E,E], bproj [E] and shortcut `res` when given); returns [B,H,W,E]."""
     lib = _lib.load()
     B, H, W, E = x.shape
     wd = wqkv.to(x.device, torch.float16).contiguous()
     bd = bqkv.to(x.device, torch.float32).contiguous()
+    wpd = wproj.to(x.device, torch.float16).contiguous() if wproj is not None else None
+    bpd = bproj.to(x.device, torch.float32).contiguous() if bproj is not None else None
     out = torch.empty(B, H, W, E, device=x.device, dtype=torch.float16)
     th, tp = _hostf(table)
-    rc = lib.rs_op_window_attention_qkv(x.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), tp, B, H, W, heads, shift, _lib.current_stream_ptr())
+    rc = lib.rs_op_window_attention_qkv(x.data_ptr(), wd.data_ptr(), bd.data_ptr(), wpd.data_ptr() if wpd is not None else None,
+                                        bpd.data_ptr() if bpd is not None else None, res.data_ptr() if res is not None else None, out.data_ptr(),
+                                        tp, B, H, W, heads, shift, _lib.current_stream_ptr())
     _lib.check(rc, "rs_op_window_attention_qkv")
     return out
 

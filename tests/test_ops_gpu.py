@@ -386,3 +386,12 @@ def test_window_attention_fused_qkv(gpu, hw, shift):
     out = ops.window_attention_qkv(xd, wqkv, bqkv, table, heads, shift)
     torch.cuda.synchronize()
     _close(out.permute(0, 3, 1, 2), ref, 3e-3, f"fused qkv window attention {hw} shift {shift}")
+    # ... with the output projection and the shortcut fused as well (swin_transformer.py:141-143,277)
+    wproj = (torch.randn(E, E, generator=g) / math.sqrt(E)).half()
+    bproj = torch.randn(E, generator=g) * 0.2
+    res = torch.randn(2, E, H, W, generator=g)
+    rd = _nhwc(res, torch.float16, gpu)
+    ref2 = torch.einsum("bchw,oc->bohw", ref.half().float(), wproj.float()) + bproj[None, :, None, None] + _ref_in(rd)
+    out2 = ops.window_attention_qkv(xd, wqkv, bqkv, table, heads, shift, wproj=wproj, bproj=bproj, res=rd)
+    torch.cuda.synchronize()
+    _close(out2.permute(0, 3, 1, 2), ref2, 3e-3, f"fused qkv + proj window attention {hw} shift {shift}")
