@@ -120,6 +120,8 @@ struct GNParams {
     float* partial;      // [B][S][32][2] partial sums
     int B, HW, C, ldx, ldy, S, groups;
     float eps; int act;
+    float* coef;         // non-null: do not normalise; write the per-(image, channel) affine [B][2][C] (scale row, then shift row)
+                         // so that a consumer kernel can apply y = x * scale + shift while it loads x (fused Swin kernels)
 };
 
 struct WinAttnParams {
@@ -139,4 +141,5 @@ struct WinAttnParams {
     const float* bproj;   // [E]
     const void* res;      // [B,H,W,ldres] fp16 shortcut, read at the same (un-shifted) pixels the result is written to
     int ldres;
+    const float* xcoef;   // optional GroupNorm affine [B][2][E] (GNParams::coef): x is the raw tensor, normalised on the fly
 };

@@ -44,7 +44,7 @@ int rs_win_attn_qkv_supported(int heads, int E);
 int rs_win_attn_qkv_launch(const WinAttnParams* p, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
-                       int ldres, int ldy, int E, int HD, hipStream_t st);
+                       int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st);
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
 int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int H, int W, int sf, int ldo, hipStream_t st);
 int rs_vq_launch(const float* z, const float* codebook, float* zq, int* idx, long long N, int NE, int D, hipStream_t st);
@@ -174,7 +174,7 @@ struct Exec {
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
     void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
-                  int ldres, int ldy, int E, int HD) {
+                  int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0) {
         igemm_flops[0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
         igemm_bytes += 2.0 * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
         ++igemm_launches;
@@ -188,7 +188,7 @@ struct Exec {
             e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
             (void)hipEventRecord(e0, st);
         }
-        check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, st), "swin_mlp");
+        check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, st), "swin_mlp");
         if (e1) (void)hipEventRecord(e1, st);
     }
 };
@@ -565,7 +565,8 @@ struct rs_engine {
     void conv1(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
         conv(ex, w, x, nullptr, y, 1, 0, 0, 1, act, res);
     }
-    void gn(Exec& ex, const GNW& g, const View& x, const View& y, float eps, int act, const float* film = nullptr) {
+    // `coef` non-null: statistics + affine coefficients only ([B][2][C] floats), y is not written (fused consumer kernels)
+    void gn(Exec& ex, const GNW& g, const View& x, const View& y, float eps, int act, const float* film = nullptr, float* coef = nullptr) {
         const int HW = x.H * x.W;
         // slab counts: enough workgroups to fill the chip, but every apply workgroup re-derives the per-channel
         // coefficients, so slabs must stay fat enough to amortise that (RS_GN_BLOCKS_* override the targets for tuning)
@@ -579,7 +580,7 @@ struct rs_engine {
         if (ex.dry) return;
         GNParams p{};
         p.x = x.p; p.y = y.p; p.gamma = g.gamma; p.beta = g.beta; p.film = film; p.partial = partial;
-        p.B = x.B; p.HW = HW; p.C = x.C; p.ldx = x.ld; p.ldy = y.ld; p.S = S; p.groups = 32; p.eps = eps; p.act = act;
+        p.B = x.B; p.HW = HW; p.C = x.C; p.ldx = x.ld; p.ldy = y.ld; p.S = S; p.groups = 32; p.eps = eps; p.act = act; p.coef = coef;
         ex.check(rs_groupnorm_launch(&p, x.dt, S2, ex.st), "groupnorm");
         ++ex.launches;
     }
@@ -632,12 +633,17 @@ struct rs_engine {
         int bi = 0;
         for (const SwinBlockW& s : b.blocks) {
             const std::string bp = "blk" + std::to_string(bi++) + ".";
-            View n = ex.T(X.B, X.H, X.W, E, X.dt);
-            gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE);
             // fp16 storage: qkv projection fused into the attention kernel (the [M][3E] tensor never reaches HBM); RS_ATTN_FUSED=0
-            // and the debug trace (which records qkv) keep the two launches
+            // and the debug trace (which records qkv) keep the two launches.  RS_GN_FOLD (default on): the fused consumer kernels
+            // also apply the GroupNorm affine while they load their input, so norm1 / norm2 only produce [B][2][E] coefficients.
             static const int attn_fused = []() { const char* v = getenv("RS_ATTN_FUSED"); return v ? atoi(v) : 2; }();
+            static const int gn_fold = []() { const char* v = getenv("RS_GN_FOLD"); return v ? atoi(v) : 1; }();
             const bool fuse_qkv = attn_fused && X.dt == RS_F16 && rs_win_attn_qkv_supported(heads, E) && s.bias_n && s.qkv.wh && !ex.trace;
+            const bool fold1 = fuse_qkv && gn_fold;
+            View n;
+            float* coef1 = nullptr;
+            if (fold1) { coef1 = (float*)ex.raw((size_t)X.B * 2 * E * sizeof(float)); gn(ex, s.n1, e, e, 1e-5f, RS_ACT_NONE, nullptr, coef1); }
+            else { n = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE); }
             View qkv;
             if (!fuse_qkv) {
                 qkv = ex.T(X.B, X.H, X.W, 3 * E, X.dt);
@@ -652,7 +658,8 @@ struct rs_engine {
                     WinAttnParams p{};
                     p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
                     p.scale = 1.0f / std::sqrt((float)(E / heads));
-                    p.x = n.p; p.ldx = n.ld; p.wqkv = s.qkv.wh; p.bqkv = s.qkv.bias;
+                    if (fold1) { p.x = e.p; p.ldx = e.ld; p.xcoef = coef1; } else { p.x = n.p; p.ldx = n.ld; }
+                    p.wqkv = s.qkv.wh; p.bqkv = s.qkv.bias;
                     if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.wh; p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld; }
                     else { p.out = a.p; p.ldo = a.ld; }
                     ex.win_attn_qkv(p, E);
@@ -669,17 +676,25 @@ struct rs_engine {
                 conv1(ex, s.proj, a, e2, &e);
             }
             ex.tr(bp + "proj", e2);
-            View n2 = ex.T(X.B, X.H, X.W, E, X.dt);
-            gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE);
             View e3;
             // fp16 storage: one fused launch, the [M][4E] hidden tensor never reaches HBM (swin_mlp.hip); RS_MLP_FUSED=0 or a
             // small token count (RS_MLP_FUSED_MINM) keep the two GEMMs
             static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 1; }();
             static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 16384; }();   // (8192 tokens: 32 us fused vs 14 + 15 us apart)
             const int Mtok = X.B * X.H * X.W;
-            if (mlp_fused && X.dt == RS_F16 && rs_swin_mlp_supported(E, s.fc1.Cout) && s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.wh && s.fc2.wh) {
+            const bool fuse_mlp = mlp_fused && X.dt == RS_F16 && rs_swin_mlp_supported(E, s.fc1.Cout) && s.fc2.Cout == E && Mtok >= mlp_minm &&
+                                  s.fc1.wh && s.fc2.wh;
+            const bool fold2 = fuse_mlp && gn_fold && !ex.trace && (X.H * X.W) % 128 == 0;
+            View n2;
+            float* coef2 = nullptr;
+            if (fold2) { coef2 = (float*)ex.raw((size_t)X.B * 2 * E * sizeof(float)); gn(ex, s.n2, e2, e2, 1e-5f, RS_ACT_NONE, nullptr, coef2); }
+            else { n2 = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE); }
+            if (fuse_mlp) {
                 e3 = ex.T(X.B, X.H, X.W, E, X.dt);
-                if (!ex.dry) ex.swin_mlp(n2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout);
+                if (!ex.dry) {
+                    if (fold2) ex.swin_mlp(e2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, e2.ld, e2.ld, e3.ld, E, s.fc1.Cout, coef2, X.H * X.W);
+                    else ex.swin_mlp(n2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout);
+                }
             } else {
                 View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
                 conv1(ex, s.fc1, n2, f, nullptr, RS_ACT_GELU);
@@ -1437,7 +1452,7 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
 
 int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
                    int M, int E, int HD, void* stream) {
-    const int rc = rs_swin_mlp_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, (hipStream_t)stream);
+    const int rc = rs_swin_mlp_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, (hipStream_t)stream);
     if (rc) fail("swin_mlp launch rejected the shape (fp16, E = 192, HD = 768 only)");
     return rc;
 }

@@ -158,6 +158,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
         ca[c] = a; cb[c] = bb;
     }
     __syncthreads();
+    if (p.coef) {   // coefficient-only mode (launched with one slab per image): hand the affine to the consumer kernel
+        for (int c = tid; c < p.C; c += 256) { p.coef[((long long)b * 2) * p.C + c] = ca[c]; p.coef[((long long)b * 2 + 1) * p.C + c] = cb[c]; }
+        return;
+    }
     if (p.act == RS_ACT_SILU) gn_apply_rows<T, RS_ACT_SILU>(p, ca, cb, b);
     else if (p.act == RS_ACT_GELU) gn_apply_rows<T, RS_ACT_GELU>(p, ca, cb, b);
     else gn_apply_rows<T, RS_ACT_NONE>(p, ca, cb, b);
@@ -234,6 +238,10 @@ __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (
         }
     }
     __syncthreads();
+    if (p.coef) {   // coefficient-only mode
+        for (int c = tid; c < SC; c += NT) { p.coef[((long long)b * 2) * p.C + cs + c] = ca[c]; p.coef[((long long)b * 2 + 1) * p.C + cs + c] = cb[c]; }
+        return;
+    }
     if (!active) return;
     float a[8], c[8];
 #pragma unroll
@@ -305,7 +313,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
-    dim3 g1(p.S, p.B), g2(apply_slabs, p.B);
+    dim3 g1(p.S, p.B), g2(p.coef ? 1 : apply_slabs, p.B);
     const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
     if (dt == RS_F16) {
         hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
@@ -637,6 +645,25 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the window's tokens are in LDS
+    if (p.xcoef) {
+        // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c], rounded to fp16 exactly where the separate apply kernel
+        // rounds.  64 rows x 24 chunks of 8 channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
+        const float* sc = p.xcoef + (long long)b * 2 * E;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int item = tid + 384 * q;              // 0 .. 1535
+            const int st = item >> 9, t = (item >> 3) & 63, ps = item & 7;
+            const int c0 = st * 64 + ((ps ^ (t & 7)) << 3);
+            f16x8* cell = (f16x8*)(smem + st * XS_STAGE + t * 128 + ps * 16);
+            f16x8 v = *cell;
+            const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
+            const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (f16)fmaf((float)v[e], a0[e], d0[e]); v[4 + e] = (f16)fmaf((float)v[4 + e], a1[e], d1[e]); }
+            *cell = v;
+        }
+        __syncthreads();
+    }
     f16x8 kf[4], qf[4];
     {
         f32x4 acc[2][4];

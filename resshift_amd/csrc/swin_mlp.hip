@@ -27,6 +27,8 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
 struct MlpParams {
     const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
     int M, ldx, ldres, ldy;
+    const float* xcoef;   // optional GroupNorm affine [B][2][E] (GNParams::coef): x is the raw tensor, normalised while it is loaded
+    int HW;               // tokens per image (a multiple of the 128-token tile whenever xcoef is set)
 };
 
 template <int E, int HD>
@@ -74,6 +76,22 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         const f16* xr = p.x + (long long)m * p.ldx + lg * 8;
 #pragma unroll
         for (int ks = 0; ks < 2 * KS1; ++ks) xf[ks][j] = *(const f16x8*)(xr + ks * 32);
+    }
+    if (p.xcoef) {   // GroupNorm (norm2) folded in, rounded to fp16 exactly where the separate apply kernel rounds
+        const float* sc = p.xcoef + (long long)(m0 / p.HW) * 2 * E;
+#pragma unroll
+        for (int ks = 0; ks < 2 * KS1; ++ks) {
+            const int c0 = ks * 32 + lg * 8;
+            const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
+            const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xf[ks][j][e] = (f16)fmaf((float)xf[ks][j][e], a0[e], d0[e]);
+                    xf[ks][j][4 + e] = (f16)fmaf((float)xf[ks][j][4 + e], a1[e], d1[e]);
+                }
+        }
     }
     // fc1 bias of the chunk being processed, fetched one chunk ahead
     f32x4 bcur[2], bnxt[2];
@@ -198,11 +216,12 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
 extern "C" int rs_swin_mlp_supported(int E, int HD) { return E == 192 && HD == 768; }
 
 extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
-                                  int M, int ldx, int ldres, int ldy, int E, int HD, hipStream_t st) {
+                                  int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st) {
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
+    if (xcoef && (HW <= 0 || HW % 128)) return -2;
     MlpParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
-    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
     constexpr int LDS = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
