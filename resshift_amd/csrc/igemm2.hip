@@ -1,13 +1,18 @@
-// Implicit-GEMM kernel, second generation: same formulation / operand gather / epilogue as igemm.hip, but the K
-// pipeline is built for latency hiding on CDNA4:
-//   * 512 threads = 8 waves (4 pixel-waves x 2 channel-waves), tile BP x BC with BP in {128,256};
-//   * operands travel global -> LDS with `global_load_lds_dwordx4` (LDS-DMA): no VGPR staging, no ds_write pass.
+// Implicit-GEMM kernel, second generation: same formulation / operand gather / LDS image as igemm.hip, but
+//   * operands travel global -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA): no VGPR staging, no ds_write pass.
 //     The LDS image of one instruction is lane-linear (wave-uniform base + lane*16 B), so the XOR swizzle that keeps
 //     the ds_read_b128 fragment reads conflict-free is applied on the SOURCE side: lane (row r, slot c) fetches the
-//     K-chunk c ^ (r & 7) — free here because every lane computes its own gather address anyway;
-//   * NS = 3 stage ring, prefetch distance 2 stages, counted `s_waitcnt vmcnt(L)` + raw `s_barrier` (one barrier per
-//     stage; never vmcnt(0) inside the main loop), out-of-image / out-of-range lanes read a 16-byte zero buffer so
-//     that every wave issues exactly L loads per stage and the counted waits stay valid.
+//     K-chunk c ^ (r & 7) - free here because every lane computes its own gather address anyway.  Out-of-image taps,
+//     ragged rows and the K tail use a byte offset beyond the descriptor's num_records: the hardware returns zeros;
+//   * template <TI, TO, BP, BC, NS, NWV>: BP x BC output tile, NS-slot ring, NWV waves (NWV/2 pixel-waves x 2
+//     channel-waves).  Default instantiation: 128 x {128,160,192}, 2 slots, 8 waves, <= 80 KB of LDS and <= 128 VGPRs so
+//     that TWO workgroups share a CU and overlap each other's prologue / barrier / epilogue phases; 64 x BC on 4 waves for
+//     the 16x16 / 8x8 levels (split-K); the deeper rings / 256-pixel / 16-wave instantiations are kept behind environment
+//     knobs for A/B runs (profiles/r1_igemm_ablation.txt);
+//   * raw `s_barrier` + counted `s_waitcnt vmcnt` (never __syncthreads() in the K loop: its fence would drain the DMA
+//     prefetch), one barrier per K stage; stages 0 and 1 are issued together in the prologue;
+//   * epilogue: bias / residual fetched up front, activation chosen at compile time behind one uniform branch, fragments
+//     finished one at a time (register budget), fp16 results transposed through LDS into 16-byte NHWC stores.
 #include "igemm_common.h"
 #include <algorithm>
 #include <type_traits>
