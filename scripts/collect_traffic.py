@@ -1,5 +1,5 @@
 """Turn two rocprofv3 --pmc CSVs (FETCH_SIZE pass, WRITE_SIZE pass) of bench.py into profiles/<name>.json with the HBM
-traffic of the implicit-GEMM kernel family per launch.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM):
+traffic of the MFMA implicit-GEMM kernel family (incl. the fused Swin kernels, as in bench.py's roofline) per launch.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM):
 counter unit = KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> x2; WRITE_SIZE taken as is.
 
     python scripts/collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
@@ -9,13 +9,13 @@ import csv, json, sys
 def total(path, counter):
     s = 0.0; n = 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "igemm" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("igemm", "swin_mlp", "win_attn_qkv")):
             s += float(r["Counter_Value"]); n += 1
     return s, n
 
 f, nf = total(sys.argv[1], "FETCH_SIZE")
 w, nw = total(sys.argv[2], "WRITE_SIZE")
-out = {"kernel_family": "igemm*_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
+out = {"kernel_family": "igemm*_kernel + swin_mlp_kernel + win_attn_qkv_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_per_launch": 2.0 * f * 1024 / max(1, nf), "write_bytes_per_launch": w * 1024 / max(1, nw),
        "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units, separate --pmc passes"}
 out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
