@@ -230,7 +230,7 @@ def main():
             ms32 = (time.perf_counter() - t0) / 2 * 1e3
             par32.update({"ms_per_step": round(ms32, 2), "images_per_sec": round(B / ms32 * 1e3, 2), "steps_timed": 2})
             parity.append(par32)
-            # ... and the cheapest mixture that stays above the 60 dB bar in the precision sweep: the last 8 UNet steps exact
+            # ... and a mixture in between (the last 8 UNet steps exact): how fast the VQ code agreement recovers with precision
             pm = policy_args("mixed8", steps)
             parm = parity_of("mixed8 (last 8 UNet steps fp32, rest fp16)", *pm)
             torch.cuda.synchronize()
