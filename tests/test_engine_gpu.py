@@ -319,3 +319,29 @@ def test_inference_files_on_device_uint8(gpu, tmp_path):
         lq = s.engine.u8_to_input(v[None].to(gpu))
         exp = s.engine.output_to_u8(s.sample_tiled(lq, noise_repeat=True)).cpu()[0]
         assert torch.equal(out, exp)
+
+
+def test_fused_swin_paths_match_unfused(gpu, tmp_path):
+    """The fused Swin kernels (qkv + attention + projection, MLP) and the GroupNorm fold against the one-kernel-per-op path
+    on a full-size fp16 UNet forward.  The knobs are read once per process, hence the subprocesses.  Folding GroupNorm into
+    the consumers must not change a bit; fusing the GEMMs only reorders fp32 accumulation."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(tag, **env):
+        out = tmp_path / f"{tag}.pt"
+        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        subprocess.run([sys.executable, os.path.join(here, "_unet_once.py"), str(out)], check=True, env=e, timeout=300)
+        return torch.load(out)
+
+    fused = run("fused")
+    nofold = run("nofold", RS_GN_FOLD=0)
+    plain = run("plain", RS_GN_FOLD=0, RS_ATTN_FUSED=0, RS_MLP_FUSED=0)
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, nofold), "folding GroupNorm into the fused kernels changed the result"
+    err = H.rel_err(fused, plain)
+    print(f"fused vs unfused Swin path: rel err {err:.2e}")
+    assert err < 5e-3
