@@ -11,8 +11,13 @@
 // (they are L2-resident: every workgroup streams the same 590 KB); the token fragments stay in registers.  Same LDS image / swizzle / MFMA operand
 // roles as igemm2.hip: weights are the A operand, tokens the B operand, so a lane ends with 4 consecutive output
 // channels of one token.
+// (A variant with wave-private token rows that keeps the hidden chunk in registers - GEMM1's accumulators reused as GEMM2's
+// B operand through a consistent k-permutation, no P round trip, one barrier per chunk - was measured at 180 us against
+// 146 us for this kernel at 131072 tokens: every wave then reads the whole W1 and W2 chunk from LDS, 72 LDS instructions
+// per chunk per wave.  profiles/r1_igemm_ablation.txt.)
 #include "igemm_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
