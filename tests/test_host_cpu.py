@@ -215,3 +215,30 @@ def test_tile_origins_known_answers():
     for (length, pch, stride), exp in cases.items():
         assert extract_starts(length, pch, stride) == exp
         assert oc.tile_starts(length, pch, stride) == exp
+
+
+def test_blob_cache_file_format_roundtrip_and_rejection(tmp_path):
+    """sharding._blob_cache_save / _blob_cache_load: header (magic + byte count) + raw blob; stale or damaged files are
+    ignored so that the caller falls back to the checkpoints (the GPU test covers the end-to-end path)."""
+    from resshift_amd import sharding
+
+    class FakeEngine:
+        def __init__(self, n):
+            self.blob = torch.arange(n, dtype=torch.int64).to(torch.uint8)
+
+        def weight_blob(self):
+            return self.blob
+
+    src = FakeEngine(4099)
+    path = str(tmp_path / "w.rsblob")
+    sharding._blob_cache_save(path, src)
+    dst = FakeEngine(4099)
+    dst.blob.zero_()
+    assert sharding._blob_cache_load(path, dst) and torch.equal(dst.blob, src.blob)
+    assert not sharding._blob_cache_load(path, FakeEngine(4100))          # another configuration: different blob size
+    assert not sharding._blob_cache_load(str(tmp_path / "missing"), dst)
+    raw = open(path, "rb").read()
+    open(path, "wb").write(b"XXXXXXXX" + raw[8:])                          # foreign magic
+    assert not sharding._blob_cache_load(path, dst)
+    open(path, "wb").write(raw[:-5])                                        # truncated
+    assert not sharding._blob_cache_load(path, dst)
