@@ -213,21 +213,22 @@ def test_tiled_large_image_path(gpu):
                      autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=None, params=ap))
     s = ResShiftSampler(cfg, sf=4, use_amp=False, chop_size=16, chop_stride=12, chop_bs=2, padding_offset=16, seed=1,
                         state_dicts={"model": usd, "autoencoder": asd})
-    gen = torch.Generator().manual_seed(3)
-    y = torch.rand(1, 3, 40, 28, generator=gen) * 2 - 1
-    n_tiles = len(oc.tile_starts(40, 16, 12)) * len(oc.tile_starts(28, 16, 12))
-    n_calls = (n_tiles + 1) // 2
-    calls = []
-    for k in range(n_calls):
-        nb = min(2, n_tiles - 2 * k)  # tiles in this call (true batch is 1)
-        calls.append([torch.randn(nb, 3, 16, 16, generator=gen) for _ in range(dp["steps"] + 1)])
+    from oracle import make_golden_tiled as mt   # the very inputs of tests/golden/reference_tiled.npz
+
+    y, calls = mt.tiled_inputs(dp["steps"])
+    n_calls = len(calls)
+    n_tiles = sum(c[0].shape[0] for c in calls)
     ref = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=16, chop_stride=12, chop_bs=2, padding_offset=16)
     out = s.sample_tiled(y.to(gpu), tile_noises=[(c[0].to(gpu), [n.to(gpu) for n in c[1:]]) for c in calls])
     torch.cuda.synchronize()
     assert tuple(out.shape) == (1, 3, 160, 112)
     p = H.psnr(out.cpu(), ref)
-    print(f"tiled path: {n_tiles} tiles in {n_calls} calls, PSNR {p:.1f} dB")
-    assert p >= 60.0
+    import os
+
+    gold = torch.from_numpy(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_tiled.npz"))["sample"])
+    pg = H.psnr(out.cpu(), gold)   # the reference's own ImageSpliterTh + modules (oracle/make_golden_tiled.py)
+    print(f"tiled path: {n_tiles} tiles in {n_calls} calls, PSNR {p:.1f} dB vs oracle, {pg:.1f} dB vs the reference output")
+    assert p >= 60.0 and pg >= 60.0
 
 
 def test_u8_pre_and_post_processing_on_device(gpu):

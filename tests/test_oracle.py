@@ -137,3 +137,20 @@ def test_tiling_restatements_against_reference_ImageSpliterTh():
                 res[:, :, h0:h1, w0:w1] += out[t * 2:(t + 1) * 2]
                 cnt[:, :, h0:h1, w0:w1] += 1
         assert torch.equal(r.gather(), res / cnt)
+
+
+def test_tiled_path_oracle_vs_reference_golden():
+    """tests/golden/reference_tiled.npz was produced by the reference's own ImageSpliterTh + UNet / VQ-AE / diffusion loop
+    (oracle/make_golden_tiled.py); the oracle's tiled restatement must reproduce it wherever the tests run."""
+    import os
+
+    from oracle import make_golden_tiled as mt
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_tiled.npz"))
+    assert list(g["meta"]) == [mt.CHOP_SIZE, mt.CHOP_STRIDE, mt.CHOP_BS, mt.PAD_OFFSET, mt.SEED]
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    y, calls = mt.tiled_inputs(dp["steps"])
+    got = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=mt.CHOP_SIZE, chop_stride=mt.CHOP_STRIDE, chop_bs=mt.CHOP_BS,
+                          padding_offset=mt.PAD_OFFSET)
+    assert (got - torch.from_numpy(g["sample"])).abs().max().item() <= 2e-5
