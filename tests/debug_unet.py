@@ -1,9 +1,10 @@
-"""GPU-side bisect helper: engine debug trace vs oracle intermediates for a tiny UNet (not a test)."""
+"""GPU-side bisect helper: engine debug trace vs oracle intermediates for a tiny UNet (a checker tool, not a collected test;
+it lives under tests/ because only test infrastructure may import oracle/).    python tests/debug_unet.py [case] [fp32|fp16]"""
 import os, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import helpers as H
 from oracle import resshift_oracle as oc
 from resshift_amd import UNetModelSwin
