@@ -242,3 +242,67 @@ def test_blob_cache_file_format_roundtrip_and_rejection(tmp_path):
     assert not sharding._blob_cache_load(path, dst)
     open(path, "wb").write(raw[:-5])                                        # truncated
     assert not sharding._blob_cache_load(path, dst)
+
+
+def _kernel_resource_table(lib_path):
+    """vgpr / spill / scratch figures of every gfx950 kernel in the built library: the clang offload bundles inside the .so are
+    walked by hand (magic, entry table), each code object's metadata notes are read with llvm-readelf."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    data = open(lib_path, "rb").read()
+    table, pos = {}, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        q = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            triple = data[q:q + tl].decode()
+            q += tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as fh:
+                fh.write(data[i + off:i + off + size])
+                fh.flush()
+                txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", fh.name], capture_output=True, text=True).stdout
+            for blk in re.split(r"\n\s*- \.agpr_count", txt)[1:]:
+                d = dict(re.findall(r"\.(name|vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s*(\S+)", blk))
+                if "name" in d:
+                    table[d["name"]] = {k: int(v) for k, v in d.items() if k != "name"}
+        pos = i + 24
+    return table
+
+
+def test_kernel_register_budgets():
+    """Occupancy assumptions of DESIGN.md as a build-time regression check (no GPU needed): the default implicit-GEMM
+    instantiation lives on two workgroups per CU (4 waves per SIMD: <= 128 VGPRs), and none of the hot kernels may spill."""
+    import os
+
+    from resshift_amd import _lib
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    t = _kernel_resource_table(_lib.LIB_PATH)
+    assert len(t) > 50
+
+    def find(*parts):
+        hits = [v for k, v in t.items() if all(p in k for p in parts)]
+        assert hits, parts
+        return hits
+
+    for bc in (128, 160):
+        for k in find("igemm2_kernelIDF16_DF16_Li128E", f"Li{bc}ELi2ELi8E"):
+            assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0, (bc, k)
+    for k in find("igemm2_kernelIDF16_DF16_Li128E", "Li192ELi2ELi8E"):
+        assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] <= 4, k
+    for name in ("igemm3_kernelIDF16_Li160E", "igemm3_kernelIDF16_Li128E", "swin_mlp_kernel", "win_attn_qkv_kernel", "win_attn_mfma_kernel",
+                 "gn_fused_kernelIDF16_Li12ELi256E", "gn_apply_kernelIDF16_", "gn_stats_kernelIDF16_"):
+        for k in find(name):
+            assert k["vgpr_count"] <= 256 and k["vgpr_spill_count"] == 0, (name, k)
