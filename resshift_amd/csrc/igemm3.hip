@@ -272,8 +272,10 @@ __global__ __launch_bounds__(512, 2) void igemm3_kernel(IGemmParams p) {
             if (vec_ok && n + 7 < p.Cout) {
                 *(uint4*)yp = v;
             } else {
-                const f16* hv = (const f16*)&v;
-                for (int r = 0; r < 8 && n + r < p.Cout; ++r) yp[r] = (TO)hv[r];
+                const f16x8 hv = __builtin_bit_cast(f16x8, v);   // (no address-of: a pointer into `v` would park it in scratch memory)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (n + r < p.Cout) yp[r] = (TO)hv[r];
             }
         }
     } else {

@@ -299,7 +299,7 @@ def test_kernel_register_budgets():
 
     for bc in (128, 160):
         for k in find("igemm2_kernelIDF16_DF16_Li128E", f"Li{bc}ELi2ELi8E"):
-            assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0, (bc, k)
+            assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (bc, k)
     for k in find("igemm2_kernelIDF16_DF16_Li128E", "Li192ELi2ELi8E"):
         assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] <= 4, k
     for name in ("igemm3_kernelIDF16_Li160E", "igemm3_kernelIDF16_Li128E", "swin_mlp_kernel", "win_attn_qkv_kernel", "win_attn_mfma_kernel",
