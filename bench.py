@@ -1,22 +1,31 @@
 #!/usr/bin/env python
 """Benchmark of the ResShift sampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision POLICY]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision POLICY] [--config NAME]
 
-Workload (BASELINE.json configs[1]): realsr_swinunet_realesrgan256, 64x64 -> 256x256, 15 diffusion steps, batch 32
-per GPU, random-init weights, synthetic inputs already resident in HBM.  One "step" of this benchmark = one pass of
-the whole hot path over one batch: bicubic x4 -> VQ-f4 encode -> prior sample -> 15 x (Swin-UNet + posterior update)
--> VQ lookup -> VQ-f4 decode, i.e. one `rs_sample` call of the engine.
+Workload (BASELINE.json configs[1], the default): realsr_swinunet_realesrgan256, 64x64 -> 256x256, 15 diffusion steps,
+batch 32 per GPU, random-init weights, synthetic inputs already resident in HBM.  One "step" of this benchmark = one
+pass of the whole hot path over one batch: bicubic x4 -> VQ-f4 encode -> prior sample -> 15 x (Swin-UNet + posterior
+update) -> VQ lookup -> VQ-f4 decode, i.e. one `rs_sample` call of the engine.  `--config` selects the other BASELINE
+configurations (journal: 4 steps; faceir: 512x512, f8 autoencoder, batch 16; inpaint: 256x256 + mask, batch 16).
 
 For N > 1 the driver launches one process per GPU (torchrun); rank 0 packs the weights and the blob reaches the other
 ranks through ONE RCCL broadcast; every rank then processes its own batch (weak scaling, no data-path collective).
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (MFMA implicit-GEMM kernel family, hipEvent
-timed on the launch stream in a dedicated pass) and `cpu_baseline` (the CPU oracle timed on this host, N=1 only).
+Rank 0 prints ONE JSON line with the contract fields plus
+  * `roofline`      MFMA implicit-GEMM kernel family (hipEvent timed on the launch stream in a dedicated pass) and, under
+                    `roofline.groupnorm`, the HBM-bound GroupNorm family measured the same way;
+  * `cpu_baseline`  the CPU oracle timed on this host (N = 1 only, bounded sample);
+  * `parity_vs_cpu_oracle` / `value_at_parity`  image PSNR, latent PSNR and VQ code agreement of the headline policy and of
+                    the parity-qualified policy (split-precision encoder + UNet, fp16 decoder) against the CPU oracle on the
+                    first images of the batch, and the throughput of that policy;
+  * `torch_rocm_autocast_baseline`  the same restatement of the reference run with stock PyTorch-ROCm ops on this GPU under
+                    torch.autocast(fp16) (what sampler.py:185 does): its images/sec and ITS parity against the fp32 CPU path.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,15 +45,28 @@ from resshift_amd.gaussian_diffusion import create_gaussian_diffusion  # noqa: E
 from resshift_amd.spec import ae_param_spec, random_state_dict, unet_param_spec  # noqa: E402
 from resshift_amd.unet import UNetModelSwin  # noqa: E402
 
-CONFIG = "realsr_swinunet_realesrgan256"
-GFLOP_PER_IMAGE = 2535.7          # UNet 101.32 x 15 + encoder 345.24 + decoder 670.58 (2*MAC)
-MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# name -> (yaml, LR side, default batch, algorithmic GFLOP per image [SURVEY.md §6 / §8(d), 2*MAC], description)
+CONFIGS = {
+    "realsr": ("realsr_swinunet_realesrgan256", 64, 32, 2535.7, "1x3x64x64 LR -> 3x256x256, 15 steps"),
+    "journal": ("realsr_swinunet_realesrgan256_journal", 64, 32, 1421.1, "1x3x64x64 LR -> 3x256x256, 4 steps"),
+    "faceir": ("faceir_gfpgan512_lpips", 512, 16, 1891.6, "1x3x512x512 -> 3x512x512 face restoration, f8 autoencoder, 4 steps"),
+    "inpaint": ("inpaint_lama256_imagenet", 256, 16, 1426.7, "1x3x256x256 + mask -> 3x256x256 inpainting, 4 steps"),
+}
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md; "split" = three fp16 MFMAs per product
+MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "split": 2500.0 / 3.0}
+HBM_PEAK_GBS = 8000.0
 
-# precision policies: which kernels run fp16-storage MFMA and which run the exact fp32 MFMA
+# precision policies: which parts run fp16-storage MFMA, the exact fp32 MFMA, or split storage ((hi, lo) fp16 pairs, three
+# fp16 MFMAs per product: fp32-class GEMMs at 1/3 of the fp16 matrix rate)
 POLICIES = {
     "fp16": dict(unet="fp16", encode="fp16", decode="fp16"),
     "fp32": dict(unet="fp32", encode="fp32", decode="fp32"),
+    "split": dict(unet="split", encode="split", decode="split"),
+    # the parity-qualified policy: everything in front of the VQ argmin (ldm/modules/vqvae/quantize.py:276-285) fp32-class,
+    # the decoder behind it in fp16
+    "parity": dict(unet="split", encode="split", decode="fp16"),
 }
+PARITY_POLICY = "parity"
 
 
 def policy_args(name: str, steps: int):
@@ -52,7 +74,7 @@ def policy_args(name: str, steps: int):
         p = POLICIES[name]
         return [p["unet"]] * steps, p["encode"], p["decode"]
     if name.startswith("mixed"):
-        # "mixed<k>": the last k timesteps (t = k-1 .. 0) and the encoder in fp32, everything else fp16
+        # "mixed<k>": the last k timesteps (t = k-1 .. 0) in fp32, everything else fp16
         k = int(name[5:] or 1)
         return ["fp32" if t < k else "fp16" for t in range(steps)], "fp16", "fp16"
     raise SystemExit(f"unknown precision policy {name}")
@@ -67,16 +89,31 @@ def log(msg: str) -> None:
         print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def kernel_source_digest() -> str:
+    """sha256 over the HIP sources: PMC traffic files under profiles/ are stamped with it and ignored when it differs"""
+    from resshift_amd import build as _b
+
+    return _b._digest()[:16]
+
+
+def psnr_db(a, b, p2p):
+    mse = torch.mean((a.double() - b.double()) ** 2).item()
+    return float("inf") if mse == 0 else float(10 * np.log10(p2p * p2p / mse))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--config", default="realsr", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the config's BASELINE batch)")
     ap.add_argument("--precision", default=os.environ.get("RESSHIFT_PRECISION", "fp16"))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-images", type=int, default=8, help="images of the batch compared with the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline / parity legs)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the fp32-policy parity/timing leg")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
     args = ap.parse_args()
 
     world, rank = sharding.init_distributed()
@@ -85,10 +122,12 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.set_grad_enabled(False)
 
-    cfg = to_plain(load_config(CONFIG))
+    cname, lr_side, def_batch, gflop_per_image, cdesc = CONFIGS[args.config]
+    cfg = to_plain(load_config(cname))
     up, aep, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
     steps = int(dp["steps"])
-    B = args.batch
+    B = args.batch or def_batch
+    with_mask = bool(up.get("cond_mask", False))
 
     # ---- models: rank 0 creates random-init weights of the architecture and packs them; one RCCL broadcast
     model = UNetModelSwin(**up).to(dev).eval()
@@ -110,17 +149,31 @@ def main():
     diffusion.set_precision(pu, pe, pd)
     tables = diffusion.step_tables()
 
-    # ---- synthetic inputs resident in HBM (different per rank)
+    # ---- synthetic inputs resident in HBM (different per rank); SURVEY.md §8(d) input recipe
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    y = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
-    noise = torch.randn(steps + 1, B, 3, 64, 64, generator=g).to(dev)
+    f = 2 ** (len(aep["ddconfig"]["ch_mult"]) - 1)
+    hz = lr_side * diffusion.sf // f
+    cz = int(aep["embed_dim"])
+    y = (torch.rand(B, 3, lr_side, lr_side, generator=g) * 2 - 1).to(dev)
+    noise = torch.randn(steps + 1, B, cz, hz, hz, generator=g).to(dev)
+    mask = ((torch.rand(B, 1, lr_side, lr_side, generator=g) > 0.7).float() * 2 - 1).to(dev) if with_mask else None
 
-    def one_pass():
-        return eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, prec_unet=pu, prec_encode=pe,
-                          prec_decode=pd)
+    def run(pol, return_aux=False):
+        return eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, mask=mask, prec_unet=pol[0],
+                          prec_encode=pol[1], prec_decode=pol[2], return_aux=return_aux)
 
+    def timed(pol, n):
+        run(pol)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            run(pol)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    headline = (pu, pe, pd)
     for i in range(args.warmup):
-        out = one_pass()
+        out = run(headline)
         torch.cuda.synchronize()
         log(f"warmup pass {i} done (arena {eng.arena_bytes() / 2**30:.2f} GiB)")
     torch.cuda.synchronize()
@@ -128,7 +181,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_pass()
+        out = run(headline)
     torch.cuda.synchronize()
     sharding.barrier()
     torch.cuda.synchronize()
@@ -139,44 +192,60 @@ def main():
     value = world * B * args.steps / elapsed
     log(f"timed region done: {ms_per_step:.1f} ms/step, {value:.2f} img/s")
 
-    # ---- roofline of the dominant kernel family (MFMA implicit GEMM), measured in a dedicated pass with hipEvents
+    # ---- roofline of the dominant kernel family (MFMA implicit GEMM) and of the GroupNorm family, measured in a dedicated
+    # pass with hipEvents on the launch stream
     roofline = None
     launches = eng.last_launch_count()
     if rank == 0 and not args.no_profile_pass:
         eng.profile_enable(True)
-        one_pass()
+        run(headline)
         torch.cuda.synchronize()
         st = eng.profile_get()
         eng.profile_enable(False)
-        f16, f32 = st["flops_f16"], st["flops_f32"]
-        dom = "fp16" if f16 >= f32 else "fp32"
-        # time-weighted peak when a mixed policy runs both MFMA flavours: peak_eff = total flops / (f16/P16 + f32/P32)
-        tot = f16 + f32
-        peak_eff = tot / (f16 / MFMA_PEAK_TFLOPS["fp16"] + f32 / MFMA_PEAK_TFLOPS["fp32"]) if tot else MFMA_PEAK_TFLOPS["fp16"]
+        fl = {"fp16": st["flops_f16"], "fp32": st["flops_f32"], "split": st["flops_split"]}
+        tot = sum(fl.values())
+        dom = max(fl, key=fl.get)
+        # time-weighted peak when a policy mixes MFMA flavours: peak_eff = total flops / sum(flops_i / peak_i)
+        peak_eff = tot / sum(v / MFMA_PEAK_TFLOPS[k] for k, v in fl.items()) if tot else MFMA_PEAK_TFLOPS["fp16"]
         achieved = tot / (st["igemm_ms"] * 1e-3) / 1e12 if st["igemm_ms"] > 0 else 0.0
         # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
         # passes of this very command, corrected as MI355X_MICROARCH.md prescribes) - collected offline by
-        # scripts/collect_traffic.py into profiles/, because a process cannot attach rocprofv3 to itself
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic_igemm.json")
-        if args.precision == "fp16" and B == 32 and os.path.exists(tpath):
+        # scripts/collect_traffic.py into profiles/, because a process cannot attach rocprofv3 to itself.  The file is
+        # stamped with the digest of the kernel sources it was measured on; a stale file is not reported.
+        traffic = traffic_note = None
+        tpath = os.path.join(ROOT, "profiles", f"r2_pmc_traffic_igemm_{args.precision}.json")
+        if args.config == "realsr" and B == 32 and os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = round(json.load(fh)["hbm_bytes_per_launch"] / 1e6, 2)  # MB per launch
+                tj = json.load(fh)
+            if tj.get("kernel_source_digest") == kernel_source_digest():
+                traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)  # MB per launch
+            else:
+                traffic_note = "profiles/ PMC file was collected on different kernel sources: not reported"
         roofline = {
-            "bound": "mfma", "kernel": "igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp_kernel / win_attn_qkv_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels)", "achieved": round(achieved, 2),
-            "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
-            "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)",
+            "bound": "mfma", "kernel": "igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp_kernel / win_attn_qkv_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels)",
+            "achieved": round(achieved, 2), "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
+            "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_note": traffic_note,
             "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),
             "algorithmic_gflop_per_launch": round(tot / max(1, st["igemm_launches"]) / 1e9, 2),
             "launches_per_step": st["igemm_launches"], "avg_launch_us": round(st["igemm_ms"] * 1e3 / max(1, st["igemm_launches"]), 2),
-            "algorithmic_gflop_per_image_igemm": round(tot / B / 1e9, 1), "algorithmic_gflop_per_image_total": GFLOP_PER_IMAGE,
-            "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(GFLOP_PER_IMAGE * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
+            "algorithmic_gflop_per_image_igemm": round(tot / B / 1e9, 1), "algorithmic_gflop_per_image_total": gflop_per_image,
+            "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(gflop_per_image * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
             "dominant_precision": dom,
         }
+        if st.get("gn_launches"):
+            gbs = st["gn_bytes"] / (st["gn_ms"] * 1e-3) / 1e9 if st["gn_ms"] > 0 else 0.0
+            roofline["groupnorm"] = {
+                "bound": "hbm", "kernel": "gn_stats_kernel / gn_apply_kernel / gn_fused_kernel (GroupNorm32 + SiLU / FiLM)",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_mb_per_launch": round(st["gn_bytes"] / st["gn_launches"] / 1e6, 3),
+                "note": "algorithmic bytes = every GroupNorm input read once + every output written once",
+                "launches_per_step": st["gn_launches"], "avg_launch_us": round(st["gn_ms"] * 1e3 / st["gn_launches"], 2),
+                "ms_per_step": round(st["gn_ms"], 2), "traffic": None,
+            }
 
-    # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload
-    cpu_baseline = None
-    parity = None
+    # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload; parity
+    # of the GPU policies against it on the same images
+    cpu_baseline = parity = value_at_parity = torch_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import resshift_oracle as oc  # checker / baseline only; never on the measured GPU path
 
@@ -186,74 +255,106 @@ def main():
         except AttributeError:
             usable = os.cpu_count() or 1
         torch.set_num_threads(max(1, min(usable, torch.get_num_threads(), 64)))
-        log(f"cpu baseline: oracle on {torch.get_num_threads()} threads")
+        nb = max(1, min(args.parity_images, B))
+        log(f"cpu baseline: oracle on {torch.get_num_threads()} threads, {nb} images")
         usd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         asd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
-        nb = 2
         yc = y[:nb].cpu()
         nz = [noise[k, :nb].cpu() for k in range(steps + 1)]
+        mc = mask[:nb].cpu() if mask is not None else None
         t0 = time.perf_counter()
-        ref, ref_aux = oc.sample_loop(usd, up, asd, aep, dp, yc, nz, return_aux=True)
+        ref, ref_aux = oc.sample_loop(usd, up, asd, aep, dp, yc, nz, mask=mc, return_aux=True)
         cpu_s = time.perf_counter() - t0
+        zr = ref_aux["z_final"]
+        hw = zr.shape[2] * zr.shape[3]
 
-        def psnr_db(a, b, p2p):
-            mse = torch.mean((a.double() - b.double()) ** 2).item()
-            return float("inf") if mse == 0 else float(10 * np.log10(p2p * p2p / mse))
+        def parity_of(name, img, z, idx):
+            """image / latent PSNR and VQ code agreement against the CPU oracle (first nb images of the batch)"""
+            return {"policy": name, "images": nb,
+                    "image_psnr_db": round(psnr_db(img[:nb].float().cpu().clamp(-1, 1), ref.clamp(-1, 1), 2.0), 1),
+                    "latent_psnr_db": round(psnr_db(z[:nb].float().cpu(), zr, (zr.max() - zr.min()).item()), 1),
+                    "vq_code_agreement": round((idx.reshape(-1)[: nb * hw].cpu().long() == ref_aux["indices"].reshape(-1)).float().mean().item(), 5)}
 
-        def parity_of(policy_name, pu_, pe_, pd_):
-            """image / latent PSNR and VQ code agreement of one precision policy against the CPU oracle (first nb images)"""
-            o, aux = eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, prec_unet=pu_, prec_encode=pe_,
-                                prec_decode=pd_, return_aux=True)
+        def engine_parity(name, pol):
+            o, aux = run(pol, return_aux=True)
             torch.cuda.synchronize()
-            zr = ref_aux["z_final"]
-            hw = zr.shape[2] * zr.shape[3]
-            return {"policy": policy_name,
-                    "image_psnr_db": round(psnr_db(o[:nb].cpu().clamp(-1, 1), ref.clamp(-1, 1), 2.0), 1),
-                    "latent_psnr_db": round(psnr_db(aux["z_final"][:nb].cpu(), zr, (zr.max() - zr.min()).item()), 1),
-                    "vq_code_agreement": round((aux["indices"][: nb * hw].cpu().long() == ref_aux["indices"].reshape(-1)).float().mean().item(), 4)}
+            return parity_of(name, o, aux["z_final"], aux["indices"])
 
-        parity = [parity_of(args.precision, pu, pe, pd)]
+        parity = [engine_parity(args.precision, headline)]
         cpu_baseline = {"value": round(nb / cpu_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                        "sample": f"{nb} images, same weights/inputs/noise as the first {nb} images of the GPU batch, full 15-step loop, fp32",
+                        "what": "oracle/ (functional restatement of the reference on torch CPU ops; about 20 % FASTER than the reference "
+                                "modules' own loop at B=1, oracle/make_golden.py, so GPU/CPU ratios are understated)",
+                        "sample": f"{nb} images, same weights/inputs/noise as the first {nb} images of the GPU batch, full {steps}-step loop, fp32",
                         "seconds": round(cpu_s, 2), "gpu_vs_cpu_psnr_db": parity[0]["image_psnr_db"]}
-        # the exact-kernel policy beside it (fp32 storage, v_mfma_f32_16x16x4_f32): the configuration the >= 60 dB parity tests
-        # run; timed on the same inputs so that the price of bit-level VQ agreement is on the same line as the fp16 number
+        log(f"cpu baseline {cpu_baseline['value']} img/s; headline parity {parity[0]}")
+        # the parity-qualified policy: throughput + parity on the same inputs
+        if args.precision != PARITY_POLICY:
+            pol = policy_args(PARITY_POLICY, steps)
+            par = engine_parity(PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", pol)
+            ms = timed(pol, 3)
+            par.update({"ms_per_step": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 2), "steps_timed": 3})
+            parity.append(par)
+            log(f"parity policy: {par}")
+        qualified = [p for p in parity if p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999]
+        if qualified:
+            best = max(qualified, key=lambda p: p.get("images_per_sec", value))
+            value_at_parity = {"value": best.get("images_per_sec", round(value, 3)), "unit": "images/sec", "policy": best["policy"],
+                               "criterion": "image PSNR >= 60 dB and VQ code agreement >= 0.999 vs the CPU oracle",
+                               "image_psnr_db": best["image_psnr_db"], "vq_code_agreement": best["vq_code_agreement"], "images": nb}
+        # the exact-kernel policy beside it (fp32 storage, v_mfma_f32_16x16x4_f32)
         if args.precision != "fp32" and not args.no_exact_leg:
             p32 = policy_args("fp32", steps)
-            par32 = parity_of("fp32", *p32)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, prec_unet=p32[0], prec_encode=p32[1],
-                           prec_decode=p32[2])
-            torch.cuda.synchronize()
-            ms32 = (time.perf_counter() - t0) / 2 * 1e3
-            par32.update({"ms_per_step": round(ms32, 2), "images_per_sec": round(B / ms32 * 1e3, 2), "steps_timed": 2})
+            par32 = engine_parity("fp32 (exact fp32 MFMA everywhere)", p32)
+            ms32 = timed(p32, 1)
+            par32.update({"ms_per_step": round(ms32, 2), "images_per_sec": round(B / ms32 * 1e3, 2), "steps_timed": 1})
             parity.append(par32)
-            # ... and a mixture in between (the last 8 UNet steps exact): how fast the VQ code agreement recovers with precision
-            pm = policy_args("mixed8", steps)
-            parm = parity_of("mixed8 (last 8 UNet steps fp32, rest fp16)", *pm)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                eng.sample(y, noise, tables, sf=diffusion.sf, scale_factor=diffusion.scale_factor, prec_unet=pm[0], prec_encode=pm[1],
-                           prec_decode=pm[2])
-            torch.cuda.synchronize()
-            msm = (time.perf_counter() - t0) / 2 * 1e3
-            parm.update({"ms_per_step": round(msm, 2), "images_per_sec": round(B / msm * 1e3, 2), "steps_timed": 2})
-            parity.append(parm)
+        # SURVEY.md §8 f4: the same restatement of the reference executed by stock PyTorch-ROCm ops (MIOpen / hipBLASLt) on this
+        # GPU under torch.autocast, as sampler.py:185 runs the reference - its throughput and ITS distance from the fp32 CPU path
+        if not args.no_torch_baseline:
+            try:
+                usd_g = {k: v.to(dev) for k, v in usd.items()}
+                asd_g = {k: v.to(dev) for k, v in asd.items()}
+                nt = min(B, 8)
+                yg, ng = y[:nt], [noise[k, :nt] for k in range(steps + 1)]
+                mg = mask[:nt] if mask is not None else None
+
+                def torch_run():
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        return oc.sample_loop(usd_g, up, asd_g, aep, dp, yg, ng, mask=mg, return_aux=True)
+
+                t0 = time.perf_counter()
+                torch_run()
+                torch.cuda.synchronize()
+                first_s = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                o_t, aux_t = torch_run()
+                torch.cuda.synchronize()
+                t_s = time.perf_counter() - t0
+                tb = parity_of("torch autocast(fp16)", o_t, aux_t["z_final"], aux_t["indices"]) if nt >= nb else {}
+                torch_baseline = {"value": round(nt / t_s, 2), "unit": "images/sec", "batch": nt, "seconds": round(t_s, 3),
+                                  "first_call_seconds": round(first_s, 2),
+                                  "what": "oracle/ restatement on PyTorch-ROCm CUDA ops under torch.autocast(float16), eager",
+                                  "parity_vs_cpu_fp32": tb}
+                log(f"torch autocast baseline: {torch_baseline}")
+            except Exception as ex:  # the baseline is informational: never fail the bench line over it
+                torch_baseline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank == 0:
+        dtypes = sorted(set(pu) | {pe, pd})
         line = {
-            "metric": "images/sec (64->256 SR, 15-step ResShift sampling loop incl. VQ-f4 encode/decode)",
+            "metric": f"images/sec ({cdesc.split(',')[0]}, {steps}-step ResShift sampling loop incl. VQ encode/decode)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_diffusion_step": round(ms_per_step / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp16": "f16", "fp32": "f32"}.get(args.precision, f"f16+f32 ({args.precision})"), "data": "synthetic",
-            "config": {"workload": f"{CONFIG}: batch {B}/GPU x {world} GPU, 1x3x64x64 LR -> 3x256x256, 15 steps, random-init weights",
+            "dtype": {"fp16": "f16", "fp32": "f32", "split": "f16x2 (hi+lo pairs, 3 MFMAs per product)"}.get(dtypes[0], dtypes[0]) if len(dtypes) == 1
+                     else "+".join(dtypes) + f" ({args.precision})",
+            "data": "synthetic",
+            "config": {"workload": f"{cname}: batch {B}/GPU x {world} GPU, {cdesc}, random-init weights",
                        "precision_policy": args.precision, "kernel_launches_per_step": launches, "weight_setup_s": round(setup_s, 2),
                        "parallelism": f"dp{world} (batch sharded, one RCCL weight broadcast, no data-path collective)"},
+            "value_at_parity": value_at_parity,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
+            "torch_rocm_autocast_baseline": torch_baseline,
         }
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -15,7 +15,9 @@
  *   - work is enqueued on the caller's hipStream_t (pass torch's current stream); one engine per
  *     device, not thread-safe;
  *   - precision: RS_PREC_F16 = fp16 storage / fp32 accumulate MFMA, RS_PREC_F32 = fp32 storage /
- *     exact fp32 MFMA.
+ *     exact fp32 MFMA, RS_PREC_SPLIT = (hi, lo) fp16 pair storage (x = hi + lo * 2^-11, 4 bytes per
+ *     element) / three fp16 MFMAs per product, fp32 accumulate: fp32-class results at 1/3 of the
+ *     fp16 matrix rate (the precision that keeps the VQ codes of ldm/modules/vqvae/quantize.py:276-285).
  */
 #ifndef RESSHIFT_HIP_H
 #define RESSHIFT_HIP_H
@@ -28,6 +30,7 @@ extern "C" {
 
 #define RS_PREC_F16 0
 #define RS_PREC_F32 1
+#define RS_PREC_SPLIT 2
 #define RS_MAX_LEVELS 8
 #define RS_MAX_STEPS 64
 
@@ -63,6 +66,7 @@ typedef struct rs_config {
     int has_ae;       /* build the VQModelTorch graph    */
     int enable_f16;   /* pack fp16 weights  */
     int enable_f32;   /* pack fp32 weights (exact mode) */
+    int enable_split; /* pack (hi, lo) fp16 pair weights (RS_PREC_SPLIT) */
 } rs_config;
 
 /* Arguments of one full sampling call: gaussian_diffusion.py:367-472 (p_sample_loop) */
@@ -143,13 +147,14 @@ int rs_output_to_u8(const float* sr_f32_nchw, const float* lq_f32_nchw, const fl
 size_t rs_arena_bytes(rs_engine* e);
 long long rs_last_launch_count(rs_engine* e);
 /* profiling of the MFMA implicit-GEMM kernel family: when enabled every igemm launch of the next call is
- * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[5] = {fp16-input igemm FLOPs,
+ * bracketed by hipEvents on the launch stream.  rs_profile_get fills out[9] = {fp16-input igemm FLOPs,
  * fp32-input igemm FLOPs, summed igemm kernel milliseconds, igemm launch count, algorithmic HBM bytes (every
- * operand and result counted once)} of the last call (counts are always maintained; the time is 0 unless
+ * operand and result counted once), split-input igemm FLOPs, GroupNorm kernel milliseconds, GroupNorm count, GroupNorm
+ * algorithmic bytes (input read once + output written once)} of the last call (counts are always maintained; the time is 0 unless
  * profiling was on).  The cost of an empty event pair, measured on the same stream, is subtracted from every
  * bracket so that the sum is the kernels' own duration. */
 int rs_profile_enable(rs_engine* e, int on);
-int rs_profile_get(rs_engine* e, double* out5);
+int rs_profile_get(rs_engine* e, double* out9);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
 int rs_debug_enable(rs_engine* e, int on);
@@ -189,6 +194,9 @@ int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, in
 int rs_op_vq(const float* z, const float* codebook_dev, float* zq, int32_t* idx, long long N, int NE, int D, void* stream);
 int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out_prec, void* stream);
 int rs_op_nhwc_to_nchw(const void* in, float* out, int B, int C, int HW, int in_prec, void* stream);
+/* storage conversion of an NHWC tensor [npix][C] between any two of RS_PREC_F16 / RS_PREC_F32 / RS_PREC_SPLIT (tests feed and
+ * read split-storage tensors through it) */
+int rs_op_convert(const void* src, int src_prec, void* dst, int dst_prec, int C, long long npix, void* stream);
 
 #ifdef __cplusplus
 }

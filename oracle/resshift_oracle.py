@@ -47,7 +47,7 @@ def _linear(sd: SD, name: str, x: torch.Tensor) -> torch.Tensor:
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     # models/basic_ops.py:99-117 — cos first, then sin
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(t.device)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -104,10 +104,10 @@ def swin_block(sd: SD, name: str, x: torch.Tensor, heads: int, ws: int, shift: i
     q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
     attn = q @ k.transpose(-2, -1)
     table = sd[name + ".attn.relative_position_bias_table"]
-    bias = table[_rel_index(ws).view(-1)].view(ws * ws, ws * ws, -1).permute(2, 0, 1)
+    bias = table[_rel_index(ws).view(-1).to(table.device)].view(ws * ws, ws * ws, -1).permute(2, 0, 1)
     attn = attn + bias.unsqueeze(0)
     if shift > 0:  # the mask of a non-shifted block is identically zero
-        mask = _shift_mask(H, W, ws, shift)
+        mask = _shift_mask(H, W, ws, shift).to(attn.device)
         nW = mask.shape[0]
         attn = (attn.view(nB // nW, nW, heads, ws * ws, ws * ws) + mask[None, :, None]).view(-1, heads, ws * ws, ws * ws)
     attn = attn.softmax(dim=-1)
@@ -342,7 +342,7 @@ def sample_loop(unet_sd: SD, unet_p: dict, ae_sd: SD, ae_p: dict, dp: dict, y: t
                 xin = x / (_f32(s.sqrt_etas, i) * s.kappa * 3 + 1)
             else:
                 xin = x
-            t = torch.tensor([s.timestep_map[i]] * y.shape[0])
+            t = torch.tensor([s.timestep_map[i]] * y.shape[0], device=y.device)
             pred = unet_forward(unet_sd, unet_p, xin, t, **kwargs)  # START_X, no clipping (:278, sampler.py:156)
             mean = _f32(s.posterior_mean_coef1, i) * x + _f32(s.posterior_mean_coef2, i) * pred  # :218-221
             nonzero = 1.0 if i != 0 else 0.0

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libresshift_hip.so")
 
 RS_PREC_F16 = 0
 RS_PREC_F32 = 1
+RS_PREC_SPLIT = 2
 RS_MAX_LEVELS = 8
 RS_MAX_STEPS = 64
 
@@ -49,7 +50,7 @@ class AEConfig(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("unet", UNetConfig), ("ae", AEConfig), ("has_unet", C.c_int), ("has_ae", C.c_int), ("enable_f16", C.c_int),
-                ("enable_f32", C.c_int)]
+                ("enable_f32", C.c_int), ("enable_split", C.c_int)]
 
 
 class SampleArgs(C.Structure):
@@ -106,6 +107,7 @@ SIGNATURES = {
     "rs_op_vq": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),
     "rs_op_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "rs_op_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "rs_op_convert": (_I, [_P, _I, _P, _I, _I, _LL, _P]),
 }
 
 _lib = None

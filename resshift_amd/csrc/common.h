@@ -4,22 +4,52 @@
 // [B, H, W, C] with C contiguous.  A "pixel stride" (ld) may exceed C so that a
 // kernel can read or write a channel slice of a wider tensor (free concat).
 //
-// Two storage types are supported by every kernel:
-//   RS_F16: _Float16 storage, fp32 accumulation (v_mfma_f32_16x16x32_f16)
-//   RS_F32: float storage, exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+// Three storage types:
+//   RS_F16:  _Float16 storage, fp32 accumulation (v_mfma_f32_16x16x32_f16)
+//   RS_F32:  float storage, exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+//   RS_F16S: "split" storage - every value x is kept as TWO fp16 numbers, hi = fp16(x) and lo = fp16((x - hi) * 2^11), so
+//            that x = hi + lo * 2^-11 to a relative error <= 2^-23 (fp32 has 2^-24).  A product of two such numbers is
+//            hi*hi + 2^-11 (hi*lo + lo*hi) up to 2^-24: three fp16 MFMAs with fp32 accumulation (main + cross
+//            accumulator) give fp32-class GEMMs at 1/3 of the fp16 matrix rate instead of the 1/16 of the f32 MFMA
+//            (igemm_split.hip).  NHWC pixel record of a tensor with pixel stride ld: [ld halfs hi | ld halfs lo], i.e.
+//            4*ld bytes like fp32 storage; a channel slice at c0 starts c0 halfs into the record and keeps `ld`.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum RsDType { RS_F16 = 0, RS_F32 = 1 };
+enum RsDType { RS_F16 = 0, RS_F32 = 1, RS_F16S = 2 };
 enum RsAct { RS_ACT_NONE = 0, RS_ACT_GELU = 1, RS_ACT_SILU = 2 };
 
+// bytes of one element of a tensor (allocation size); the channel offset of a slice is rs_dtype_chan_bytes
 static inline size_t rs_dtype_size(int dt) { return dt == RS_F16 ? 2 : 4; }
+static inline size_t rs_dtype_chan_bytes(int dt) { return dt == RS_F32 ? 4 : 2; }
+
+// pointer type of split storage: pointer arithmetic counts halfs, the lo half of element i of a pixel record sits `ld`
+// halfs after its hi half
+struct h2s { unsigned short bits; };
+#define RS_LO_SCALE 2048.0f
+#define RS_LO_INV 4.8828125e-4f
+__host__ __device__ inline void rs_split(float x, f16& hi, f16& lo) {
+    hi = (f16)x;
+    lo = (f16)((x - (float)hi) * RS_LO_SCALE);   // x - hi is exact in fp32; the scaling keeps lo a NORMAL fp16 number
+}
+__device__ __forceinline__ float rs_join(f16 hi, f16 lo) { return fmaf((float)lo, RS_LO_INV, (float)hi); }
+// per storage type: pixel-record length in units of `ld` elements, and whether the cheap v_rcp / v_exp activations may
+// be used (only where the result is rounded to fp16 anyway)
+template <typename T> struct Store { static constexpr int PM = 1; static constexpr bool FAST = false; };
+template <> struct Store<f16> { static constexpr int PM = 1; static constexpr bool FAST = true; };
+template <> struct Store<h2s> { static constexpr int PM = 2; static constexpr bool FAST = false; };
+// scalar element access through a pointer to the hi part (`lo` = distance to the lo part in halfs, ignored otherwise)
+template <typename T> __device__ __forceinline__ float rs_ld(const T* p, int lo) { return (float)*p; }
+template <> __device__ __forceinline__ float rs_ld<h2s>(const h2s* p, int lo) { return rs_join(((const f16*)p)[0], ((const f16*)p)[lo]); }
+template <typename T> __device__ __forceinline__ void rs_st(T* p, int lo, float v) { *p = (T)v; }
+template <> __device__ __forceinline__ void rs_st<h2s>(h2s* p, int lo, float v) { f16 h, l; rs_split(v, h, l); ((f16*)p)[0] = h; ((f16*)p)[lo] = l; }
 
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float rs_silu(float x) { return x / (1.0f + __expf(-x)); }
@@ -61,20 +91,27 @@ template <int ACT, bool FAST> __device__ __forceinline__ float rs_act_t(float x)
     else return x;
 }
 
-template <typename T> struct Vec8;  // 8 consecutive elements of T
+template <typename T> struct Vec8;  // 8 consecutive elements of T (`lo`: see h2s; ignored by the plain types)
 template <> struct Vec8<f16> {
     f16x8 v;
-    __device__ __forceinline__ void load(const f16* p) { v = *(const f16x8*)p; }
-    __device__ __forceinline__ void store(f16* p) const { *(f16x8*)p = v; }
+    __device__ __forceinline__ void load(const f16* p, int lo = 0) { v = *(const f16x8*)p; }
+    __device__ __forceinline__ void store(f16* p, int lo = 0) const { *(f16x8*)p = v; }
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
 };
 template <> struct Vec8<float> {
     f32x4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
-    __device__ __forceinline__ void store(float* p) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
+    __device__ __forceinline__ void load(const float* p, int lo = 0) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void store(float* p, int lo = 0) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
     __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
     __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
+};
+template <> struct Vec8<h2s> {
+    f16x8 h, l;
+    __device__ __forceinline__ void load(const h2s* p, int lo) { h = *(const f16x8*)p; l = *(const f16x8*)((const f16*)p + lo); }
+    __device__ __forceinline__ void store(h2s* p, int lo) const { *(f16x8*)p = h; *(f16x8*)((f16*)p + lo) = l; }
+    __device__ __forceinline__ float get(int i) const { return rs_join(h[i], l[i]); }
+    __device__ __forceinline__ void set(int i, float x) { f16 a, b; rs_split(x, a, b); h[i] = a; l[i] = b; }
 };
 
 // ---- launch parameter blocks (plain C structs, passed by value) ------------

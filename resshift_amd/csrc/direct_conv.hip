@@ -8,7 +8,6 @@
 
 namespace {
 
-template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 
 // generic: one thread per (pixel, cout); adjacent threads = adjacent couts of the same pixel, so the
 // input reads broadcast and the weight reads / output writes coalesce.
@@ -37,16 +36,16 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvParams p) {
             if ((unsigned)ix >= (unsigned)Wv) continue;
             const long long pix = ((long long)b * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush);
             const float* wk = p.w + (long long)((ky * p.KW + kx) * Ctot) * p.Cout + co;
-            const TI* s0 = x0 + pix * p.ld0;
-            for (int c = 0; c < p.C0; ++c) acc = fmaf(ldf(s0 + c), wk[(long long)c * p.Cout], acc);
+            const TI* s0 = x0 + pix * p.ld0 * Store<TI>::PM;
+            for (int c = 0; c < p.C0; ++c) acc = fmaf(rs_ld<TI>(s0 + c, p.ld0), wk[(long long)c * p.Cout], acc);
             if (p.C1) {
-                const TI* s1 = x1 + pix * p.ld1;
+                const TI* s1 = x1 + pix * p.ld1 * Store<TI>::PM;
                 wk += (long long)p.C0 * p.Cout;
-                for (int c = 0; c < p.C1; ++c) acc = fmaf(ldf(s1 + c), wk[(long long)c * p.Cout], acc);
+                for (int c = 0; c < p.C1; ++c) acc = fmaf(rs_ld<TI>(s1 + c, p.ld1), wk[(long long)c * p.Cout], acc);
             }
         }
     }
-    ((TO*)p.y)[m * p.ldy + co] = (TO)rs_apply_act(acc, p.act);
+    rs_st<TO>((TO*)p.y + m * p.ldy * Store<TO>::PM + co, p.ldy, rs_apply_act(acc, p.act));
 }
 
 // few output channels (<= NCO): one thread per pixel, 16-byte vector loads along C, weights are
@@ -72,11 +71,11 @@ __global__ __launch_bounds__(256) void smallcout_conv_kernel(DirectConvParams p)
             const int ix = ox * p.stride - p.pad_l + kx;
             const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
             const long long pix = ok ? ((long long)b * p.Hs + (iy >> ush)) * p.Ws + (ix >> ush) : 0;
-            const TI* s0 = x0 + pix * p.ld0;
+            const TI* s0 = x0 + pix * p.ld0 * Store<TI>::PM;
             const float* wk = p.w + (long long)((ky * p.KW + kx) * p.C0) * p.Cout;
             for (int c = 0; c < p.C0; c += 8) {
                 Vec8<TI> v;
-                v.load(s0 + c);
+                v.load(s0 + c, p.ld0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xv = ok ? v.get(e) : 0.f;
@@ -87,10 +86,10 @@ __global__ __launch_bounds__(256) void smallcout_conv_kernel(DirectConvParams p)
             }
         }
     }
-    TO* y = (TO*)p.y + m * p.ldy;
+    TO* y = (TO*)p.y + m * p.ldy * Store<TO>::PM;
 #pragma unroll
     for (int o = 0; o < NCO; ++o)
-        if (o < p.Cout) y[o] = (TO)rs_apply_act(acc[o], p.act);
+        if (o < p.Cout) rs_st<TO>(y + o, p.ldy, rs_apply_act(acc[o], p.act));
 }
 
 template <typename TI, typename TO>
@@ -117,5 +116,8 @@ extern "C" int rs_direct_conv_launch(const DirectConvParams* pp, int in_dt, int 
     if (in_dt == RS_F16 && out_dt == RS_F32) return launch_direct<f16, float>(p, st);
     if (in_dt == RS_F32 && out_dt == RS_F16) return launch_direct<float, f16>(p, st);
     if (in_dt == RS_F32 && out_dt == RS_F32) return launch_direct<float, float>(p, st);
+    if (in_dt == RS_F32 && out_dt == RS_F16S) return launch_direct<float, h2s>(p, st);
+    if (in_dt == RS_F16S && out_dt == RS_F16S) return launch_direct<h2s, h2s>(p, st);
+    if (in_dt == RS_F16S && out_dt == RS_F32) return launch_direct<h2s, float>(p, st);
     return -2;
 }

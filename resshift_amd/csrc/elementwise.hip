@@ -20,7 +20,7 @@ __global__ void nchw_to_nhwc_kernel(const float* in, TO* out, int B, int C, int 
         const long long bp = g / C;  // b*HW + pix
         const long long b = bp / HW;
         const long long pix = bp - b * HW;
-        out[bp * ldo + coff + c] = (TO)(in[(b * C + c) * HW + pix] * scale);
+        rs_st<TO>(out + bp * ldo * Store<TO>::PM + coff + c, ldo, in[(b * C + c) * HW + pix] * scale);
     }
 }
 
@@ -31,7 +31,32 @@ __global__ void nhwc_to_nchw_kernel(const TI* in, float* out, int B, int C, int 
         const long long pix = g % HW;
         const long long bc = g / HW;
         const long long c = bc % C, b = bc / C;
-        out[g] = (float)in[(b * HW + pix) * ldi + coff + c];
+        out[g] = rs_ld<TI>(in + (b * HW + pix) * ldi * Store<TI>::PM + coff + c, ldi);
+    }
+}
+
+// channel-block copy between NHWC tensors of one storage type (8 channels = one 16-byte chunk per thread; C % 8 == 0)
+template <typename T>
+__global__ void copy_channels_kernel(const T* src, int lds_, T* dst, int ldd, int C, long long npix) {
+    const int nch = C >> 3;
+    const long long n = npix * nch;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const long long pix = g / nch;
+        const int c = (int)(g - pix * nch) * 8;
+        Vec8<T> v;
+        v.load(src + pix * lds_ * Store<T>::PM + c, lds_);
+        v.store(dst + pix * ldd * Store<T>::PM + c, ldd);
+    }
+}
+
+// storage conversion [npix][C] -> [npix][C] (dense tensors)
+template <typename TI, typename TO>
+__global__ void convert_kernel(const TI* src, TO* dst, int C, long long npix) {
+    const long long n = npix * C;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const long long pix = g / C;
+        const int c = (int)(g - pix * C);
+        rs_st<TO>(dst + pix * C * Store<TO>::PM + c, C, rs_ld<TI>(src + pix * C * Store<TI>::PM + c, C));
     }
 }
 
@@ -116,7 +141,7 @@ __global__ void bicubic_up_kernel(const float* in, TO* out, int B, int C, int H,
             }
             acc += r * wy[i];
         }
-        out[(((long long)b * Ho + oy) * Wo + ox) * ldo + c] = (TO)acc;
+        rs_st<TO>(out + (((long long)b * Ho + oy) * Wo + ox) * ldo * Store<TO>::PM + c, ldo, acc);
     }
 }
 
@@ -220,11 +245,21 @@ __global__ void output_to_u8_kernel(const float* __restrict__ sr, const float* _
     }
 }
 
+template <typename TI>
+static int convert_from(const TI* src, void* dst, int dst_dt, int C, long long npix, hipStream_t st) {
+    const long long n = npix * C;
+    if (dst_dt == RS_F16) hipLaunchKernelGGL((convert_kernel<TI, f16>), dim3(nblk(n)), dim3(256), 0, st, src, (f16*)dst, C, npix);
+    else if (dst_dt == RS_F16S) hipLaunchKernelGGL((convert_kernel<TI, h2s>), dim3(nblk(n)), dim3(256), 0, st, src, (h2s*)dst, C, npix);
+    else if (dst_dt == RS_F32) hipLaunchKernelGGL((convert_kernel<TI, float>), dim3(nblk(n)), dim3(256), 0, st, src, (float*)dst, C, npix);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 extern "C" {
 
 int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C, int HW, int ldo, int coff, float scale, hipStream_t st) {
     const long long n = (long long)B * C * HW;
     if (out_dt == RS_F16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, B, C, HW, ldo, coff, scale);
+    else if (out_dt == RS_F16S) hipLaunchKernelGGL((nchw_to_nhwc_kernel<h2s>), dim3(nblk(n)), dim3(256), 0, st, in, (h2s*)out, B, C, HW, ldo, coff, scale);
     else hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B, C, HW, ldo, coff, scale);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -232,8 +267,25 @@ int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C,
 int rs_nhwc_to_nchw_launch(const void* in, int in_dt, float* out, int B, int C, int HW, int ldi, int coff, hipStream_t st) {
     const long long n = (long long)B * C * HW;
     if (in_dt == RS_F16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, (const f16*)in, out, B, C, HW, ldi, coff);
+    else if (in_dt == RS_F16S) hipLaunchKernelGGL((nhwc_to_nchw_kernel<h2s>), dim3(nblk(n)), dim3(256), 0, st, (const h2s*)in, out, B, C, HW, ldi, coff);
     else hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, (const float*)in, out, B, C, HW, ldi, coff);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_copy_channels_launch(const void* src, int lds_, void* dst, int ldd, int C, long long npix, int dt, hipStream_t st) {
+    if ((C % 8) || (lds_ % 8) || (ldd % 8)) return -2;
+    const long long n = npix * (C / 8);
+    if (dt == RS_F16) hipLaunchKernelGGL((copy_channels_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, (const f16*)src, lds_, (f16*)dst, ldd, C, npix);
+    else if (dt == RS_F16S) hipLaunchKernelGGL((copy_channels_kernel<h2s>), dim3(nblk(n)), dim3(256), 0, st, (const h2s*)src, lds_, (h2s*)dst, ldd, C, npix);
+    else hipLaunchKernelGGL((copy_channels_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, (const float*)src, lds_, (float*)dst, ldd, C, npix);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_convert_launch(const void* src, int src_dt, void* dst, int dst_dt, int C, long long npix, hipStream_t st) {
+    if (src_dt == RS_F16) return convert_from((const f16*)src, dst, dst_dt, C, npix, st);
+    if (src_dt == RS_F16S) return convert_from((const h2s*)src, dst, dst_dt, C, npix, st);
+    if (src_dt == RS_F32) return convert_from((const float*)src, dst, dst_dt, C, npix, st);
+    return -2;
 }
 
 int rs_axpbypcz_launch(const float* x, const float* z, const float* n, float* y, float a, float b, float c, long long cnt, hipStream_t st) {
@@ -261,6 +313,7 @@ int rs_small_linear_launch(const float* x, const float* w, const float* bias, fl
 int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int H, int W, int sf, int ldo, hipStream_t st) {
     const long long n = (long long)B * H * sf * W * sf * C;
     if (out_dt == RS_F16) hipLaunchKernelGGL((bicubic_up_kernel<f16>), dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, B, C, H, W, sf, ldo);
+    else if (out_dt == RS_F16S) hipLaunchKernelGGL((bicubic_up_kernel<h2s>), dim3(nblk(n)), dim3(256), 0, st, in, (h2s*)out, B, C, H, W, sf, ldo);
     else hipLaunchKernelGGL((bicubic_up_kernel<float>), dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B, C, H, W, sf, ldo);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -48,6 +48,8 @@ int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const voi
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
 int rs_bicubic_launch(const float* in, void* out, int out_dt, int B, int C, int H, int W, int sf, int ldo, hipStream_t st);
 int rs_vq_launch(const float* z, const float* codebook, float* zq, int* idx, long long N, int NE, int D, hipStream_t st);
+int rs_copy_channels_launch(const void* src, int lds_, void* dst, int ldd, int C, long long npix, int dt, hipStream_t st);
+int rs_convert_launch(const void* src, int src_dt, void* dst, int dst_dt, int C, long long npix, hipStream_t st);
 }
 
 namespace {
@@ -61,7 +63,7 @@ struct View {
     void* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0, dt = RS_F16;
     long long pixels() const { return (long long)B * H * W; }
     View slice(int c0, int c) const {
-        View v = *this; v.p = (char*)p + (size_t)c0 * rs_dtype_size(dt); v.C = c; return v;
+        View v = *this; v.p = (char*)p + (size_t)c0 * rs_dtype_chan_bytes(dt); v.C = c; return v;
     }
 };
 
@@ -81,8 +83,9 @@ struct Blob {
 
 struct ConvW {
     int Cin = 0, CinP = 0, Cout = 0, KH = 1, KW = 1;
-    void* wh = nullptr; void* wf = nullptr; float* wd = nullptr; float* bias = nullptr;
+    void* wh = nullptr; void* wf = nullptr; void* ws = nullptr; float* wd = nullptr; float* bias = nullptr;
     bool direct = false;
+    const void* w_for(int dt) const { return dt == RS_F16 ? wh : (dt == RS_F16S ? ws : wf); }
 };
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResBlockW { GNW n1, n2; ConvW c1, c2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int film_off = -1; ConvW emb; };
@@ -127,12 +130,26 @@ struct Exec {
     // MFMA implicit-GEMM launches are the roofline-relevant kernel family: count their algorithmic FLOPs
     // (2*M*N*K per batch entry, K = taps*Cin as in the usual conv FLOP count) and, when profiling is on, bracket
     // every launch with hipEvents on the launch stream.
-    struct Prof { bool on = false; std::vector<hipEvent_t> ev; size_t used = 0; } * prof = nullptr;
-    double igemm_flops[2] = {0.0, 0.0};  // per input precision
+    struct Prof { bool on = false; std::vector<hipEvent_t> ev; size_t used = 0; } * prof = nullptr, *prof_gn = nullptr;
+    double gn_bytes = 0.0;               // algorithmic HBM bytes of the GroupNorm family: input read once + output written once
+    long long gn_launches = 0;
+    // event pair of one bracketed launch (null pair when profiling is off)
+    static void bracket(Prof* pr, hipStream_t st, hipEvent_t& e0, hipEvent_t& e1) {
+        e0 = e1 = nullptr;
+        if (!pr || !pr->on) return;
+        if (pr->used + 2 > pr->ev.size()) {
+            const size_t old = pr->ev.size();
+            pr->ev.resize(old + 1024);
+            for (size_t i = old; i < pr->ev.size(); ++i) (void)hipEventCreate(&pr->ev[i]);
+        }
+        e0 = pr->ev[pr->used++]; e1 = pr->ev[pr->used++];
+        (void)hipEventRecord(e0, st);
+    }
+    double igemm_flops[3] = {0.0, 0.0, 0.0};  // per input precision (fp16, fp32, split)
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
-        igemm_flops[in_dt == RS_F16 ? 0 : 1] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
+        igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
         {
             const double isz = in_dt == RS_F16 ? 2.0 : 4.0, osz = out_dt == RS_F16 ? 2.0 : 4.0;
             const double src = (double)p.B * p.Hs * p.Ws * (double)(p.C0 + p.C1) * isz;
@@ -204,9 +221,9 @@ struct rs_engine {
     std::string build_err;
     Arena arena;
     long long last_launches = 0;
-    Exec::Prof prof;
-    double last_flops[2] = {0.0, 0.0}, last_igemm_ms = 0.0, last_igemm_bytes = 0.0;
-    long long last_igemm_launches = 0;
+    Exec::Prof prof, prof_gn;
+    double last_flops[3] = {0.0, 0.0, 0.0}, last_igemm_ms = 0.0, last_igemm_bytes = 0.0, last_gn_ms = 0.0, last_gn_bytes = 0.0;
+    long long last_igemm_launches = 0, last_gn_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
     // UNet
@@ -277,6 +294,20 @@ struct rs_engine {
                         for (int ci = 0; ci < Cin; ++ci)
                             for (int t = 0; t < KH * KW; ++t)
                                 o[(size_t)co * K + (size_t)t * CinP + ci] = (f16)w[((size_t)co * Cin + ci) * KH * KW + t];
+                });
+            if (cfg.enable_split)
+                c.ws = blob.add(np * 4, [&](char* dst) {
+                    const float* w = get(); if (!w) return;
+                    f16* o = (f16*)dst;  // [Cout][K hi | K lo], lo = (w - hi) * 2^11 (common.h: split storage)
+                    for (int co = 0; co < Cout; ++co)
+                        for (int ci = 0; ci < Cin; ++ci)
+                            for (int t = 0; t < KH * KW; ++t) {
+                                f16 h, l;
+                                rs_split(w[((size_t)co * Cin + ci) * KH * KW + t], h, l);
+                                const size_t k = (size_t)t * CinP + ci;
+                                o[(size_t)co * 2 * K + k] = h;
+                                o[(size_t)co * 2 * K + K + k] = l;
+                            }
                 });
             if (cfg.enable_f32)
                 c.wf = blob.add(np * 4, [&](char* dst) {
@@ -531,6 +562,18 @@ struct rs_engine {
             splitk = rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * (x.C + C1), x.dt);
             if (splitk > 1) partial = (float*)ex.raw((size_t)splitk * M * w.Cout * sizeof(float));
         }
+        // split storage has no two-source implicit GEMM: gather the channel concatenation once (only the first conv of the
+        // feature-extractor configs, unet.py:882)
+        View xcat;
+        if (!w.direct && x1 && x.dt == RS_F16S) {
+            xcat = ex.T(x.B, x.H, x.W, x.C + C1, x.dt);
+            if (!ex.dry) {
+                ex.check(rs_copy_channels_launch(x.p, x.ld, xcat.p, xcat.ld, x.C, x.pixels(), x.dt, ex.st), "concat copy");
+                ex.check(rs_copy_channels_launch(x1->p, x1->ld, xcat.slice(x.C, C1).p, xcat.ld, C1, x.pixels(), x.dt, ex.st), "concat copy");
+            }
+            conv(ex, w, xcat, nullptr, y, stride, pad_t, pad_l, up, act, res, out_scale);
+            return;
+        }
         if (ex.dry) return;
         if (x.C + C1 != w.CinP) { if (!ex.err) { ex.err = -3; g_err = "conv input channels do not match the packed weights"; } return; }
         if (w.direct) {
@@ -543,14 +586,14 @@ struct rs_engine {
             ex.check(rs_direct_conv_launch(&p, x.dt, y.dt, ex.st), "direct_conv");
         } else {
             IGemmParams p{};
-            p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = x.dt == RS_F16 ? w.wh : w.wf; p.bias = w.bias;
+            p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = w.w_for(x.dt); p.bias = w.bias;
             p.res = res ? res->p : nullptr; p.y = y.p;
             p.C0 = x.C; p.C1 = C1; p.ld0 = x.ld; p.ld1 = x1 ? x1->ld : 0;
             p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = up; p.Ho = y.H; p.Wo = y.W; p.KH = w.KH; p.KW = w.KW;
             p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
             p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
             p.splitk = splitk; p.partial = partial;
-            if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32)"; return; }
+            if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
     }
@@ -581,7 +624,12 @@ struct rs_engine {
         GNParams p{};
         p.x = x.p; p.y = y.p; p.gamma = g.gamma; p.beta = g.beta; p.film = film; p.partial = partial;
         p.B = x.B; p.HW = HW; p.C = x.C; p.ldx = x.ld; p.ldy = y.ld; p.S = S; p.groups = 32; p.eps = eps; p.act = act; p.coef = coef;
+        ex.gn_bytes += (double)x.B * HW * x.C * (double)rs_dtype_size(x.dt) * (coef ? 1.0 : 2.0);
+        ++ex.gn_launches;
+        hipEvent_t e0, e1;
+        Exec::bracket(ex.prof_gn, ex.st, e0, e1);
         ex.check(rs_groupnorm_launch(&p, x.dt, S2, ex.st), "groupnorm");
+        if (e1) (void)hipEventRecord(e1, ex.st);
         ++ex.launches;
     }
     // models/unet.py:186-206 (use_scale_shift_norm path); eps 1e-5 (basic_ops.py:96 default GroupNorm eps)
@@ -728,7 +776,7 @@ struct rs_engine {
                 const int nz = std::min(chunk, X.B - b0);
                 const size_t boff = (size_t)b0 * T * C * es;
                 // vT[z][c][t] = sum_k Wv[c][k] n[z][t][k]   (bias folded into the PV epilogue: softmax rows sum to 1)
-                gemm_nt(ex, dt == RS_F16 ? a.v.wh : a.v.wf, 0, (char*)n.p + boff, (long long)T * C, nullptr, vT, (long long)C * T, nz, C, T, C, 1.f, dt, dt);
+                gemm_nt(ex, a.v.w_for(dt), 0, (char*)n.p + boff, (long long)T * C, nullptr, vT, (long long)C * T, nz, C, T, C, 1.f, dt, dt);
                 gemm_nt(ex, (char*)q.p + boff, (long long)T * C, (char*)k.p + boff, (long long)T * C, nullptr, S, (long long)T * T, nz, T, T, C,
                         1.0f / std::sqrt((float)C), dt, RS_F32);
                 ex.check(rs_softmax_rows_launch(S, P, dt, (long long)nz * T, T, T, T, ex.st), "softmax");
@@ -1022,11 +1070,13 @@ struct rs_engine {
         if (debug) { trace.clear(); r.trace = &trace; }
         arena.off = 0; arena.peak = 0;
         r.prof = &prof; prof.used = 0;
+        r.prof_gn = &prof_gn; prof_gn.used = 0; prof_gn.on = prof.on;
         fn(r);
         last_launches = r.launches;
-        last_flops[0] = r.igemm_flops[0]; last_flops[1] = r.igemm_flops[1]; last_igemm_launches = r.igemm_launches;
+        last_flops[0] = r.igemm_flops[0]; last_flops[1] = r.igemm_flops[1]; last_flops[2] = r.igemm_flops[2]; last_igemm_launches = r.igemm_launches;
         last_igemm_bytes = r.igemm_bytes;
         last_igemm_ms = 0.0;
+        last_gn_ms = 0.0; last_gn_bytes = r.gn_bytes; last_gn_launches = r.gn_launches;
         if (prof.on && prof.used) {
             // The event pair itself costs stream time (two marker packets bracket every launch): measure that cost with
             // empty pairs on the same stream and take it out, so that the per-launch figure is the kernel's own duration
@@ -1045,6 +1095,11 @@ struct rs_engine {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
                 last_igemm_ms += std::max(0.f, ms - overhead);
+            }
+            for (size_t i = 0; i + 1 < prof_gn.used; i += 2) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, prof_gn.ev[i], prof_gn.ev[i + 1]);
+                last_gn_ms += std::max(0.f, ms - overhead);
             }
         }
         if (r.err) return r.err;
@@ -1068,7 +1123,7 @@ rs_engine* rs_create(const rs_config* cfg) {
         if ((u.image_size >> (u.n_levels - 1)) < 8) { g_err = "coarsest UNet level must be >= 8x8"; return nullptr; }
     }
     if (cfg->has_ae && cfg->ae.n_attn_res != 0) { g_err = "AE attn_resolutions must be empty"; return nullptr; }
-    if (!cfg->enable_f16 && !cfg->enable_f32) { g_err = "enable at least one precision"; return nullptr; }
+    if (!cfg->enable_f16 && !cfg->enable_f32 && !cfg->enable_split) { g_err = "enable at least one precision"; return nullptr; }
     rs_engine* e = new rs_engine();
     e->cfg = *cfg;
     e->blob_bytes = e->build(nullptr, false);
@@ -1136,11 +1191,13 @@ size_t rs_arena_bytes(rs_engine* e) { return e ? e->arena.cap : 0; }
 int rs_profile_enable(rs_engine* e, int on) { if (!e) return -1; e->prof.on = on != 0; return 0; }
 // out[0] = fp16-input igemm FLOPs of the last call, out[1] = fp32-input igemm FLOPs, out[2] = summed igemm kernel
 // time in ms (hipEvents on the launch stream; 0 unless profiling was enabled), out[3] = igemm launch count,
-// out[4] = algorithmic HBM bytes of those launches (each operand / result counted once)
+// out[4] = algorithmic HBM bytes of those launches (each operand / result counted once), out[5] = split-input igemm FLOPs,
+// out[6..8] = GroupNorm family: summed kernel ms (events as above), launch count (one per GroupNorm), algorithmic bytes
 int rs_profile_get(rs_engine* e, double* out) {
     if (!e || !out) return -1;
     out[0] = e->last_flops[0]; out[1] = e->last_flops[1]; out[2] = e->last_igemm_ms; out[3] = (double)e->last_igemm_launches;
-    out[4] = e->last_igemm_bytes;
+    out[4] = e->last_igemm_bytes; out[5] = e->last_flops[2];
+    out[6] = e->last_gn_ms; out[7] = (double)e->last_gn_launches; out[8] = e->last_gn_bytes;
     return 0;
 }
 
@@ -1222,6 +1279,11 @@ int rs_sample(rs_engine* e, const rs_sample_args* a) {
     if (!e || !a) return fail("null argument");
     if (!e->cfg.has_ae || !e->cfg.has_unet) return fail("rs_sample needs both the UNet and the autoencoder");
     if (a->steps < 1 || a->steps > RS_MAX_STEPS) return fail("bad step count");
+    {
+        auto bad = [](int p) { return p != RS_F16 && p != RS_F32 && p != RS_F16S; };
+        if (bad(a->prec_encode) || bad(a->prec_decode)) return fail("bad precision");
+        for (int i = 0; i < a->steps; ++i) if (bad(a->prec_unet[i])) return fail("bad precision");
+    }
     hipStream_t st = (hipStream_t)a->stream;
     if (!e->ready) return fail("weights are not ready");
     const rs_ae_config& ae = e->cfg.ae;
@@ -1239,10 +1301,10 @@ int rs_sample(rs_engine* e, const rs_sample_args* a) {
         float* xt = (float*)ex.raw(zcount * 4);
         float* pred = (float*)ex.raw(zcount * 4);
         // conditioning for the UNet: raw lq at latent resolution, or the feature-extractor output (step invariant: hoisted)
-        View feat[2]; bool have_feat[2] = {false, false};
+        View feat[3]; bool have_feat[3] = {false, false, false};
         if (!e->fe_convs.empty())
             for (int i = 0; i < a->steps; ++i) {
-                const int pr = a->prec_unet[i] ? 1 : 0;
+                const int pr = a->prec_unet[i];
                 if (!have_feat[pr]) { feat[pr] = e->feature_extract(ex, a->y, a->mask, B, a->h, a->w, pr); have_feat[pr] = true; }
             }
         // encode_first_stage (gaussian_diffusion.py:500-515)
@@ -1264,7 +1326,7 @@ int rs_sample(rs_engine* e, const rs_sample_args* a) {
         }
         for (int i = a->steps - 1, k = 1; i >= 0; --i, ++k) {
             // model(_scale_input(x_t, t), t, lq) -> pred_xstart (gaussian_diffusion.py:266,278)
-            const int pr = a->prec_unet[i] ? 1 : 0;
+            const int pr = a->prec_unet[i];
             e->unet_body(ex, xt, a->inv_std[i], e->fe_convs.empty() ? nullptr : &feat[pr], a->y, a->mask, a->h, a->w, pred, B, hz, wz, pr, films[i]);
             if (!ex.dry) {
                 // mean = c1*x_t + c2*x0 (:218-221); sample = mean + [t>0]*sigma_t*eps (:358-364)
@@ -1315,6 +1377,17 @@ int rs_op_conv2d(const void* x0, const void* x1, const float* w_ref_host, const 
                 for (int ci = 0; ci < Cin; ++ci)
                     for (int t = 0; t < KH * KW; ++t) o[(size_t)co * K + (size_t)t * Cin + ci] = (f16)w_ref_host[((size_t)co * Cin + ci) * KH * KW + t];
             wdev = dev_copy(o.data(), n * 2);
+        } else if (in_prec == RS_F16S) {
+            std::vector<f16> o(2 * n);   // [Cout][K hi | K lo]
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int t = 0; t < KH * KW; ++t) {
+                        f16 h, l;
+                        rs_split(w_ref_host[((size_t)co * Cin + ci) * KH * KW + t], h, l);
+                        o[(size_t)co * 2 * K + (size_t)t * Cin + ci] = h;
+                        o[(size_t)co * 2 * K + K + (size_t)t * Cin + ci] = l;
+                    }
+            wdev = dev_copy(o.data(), n * 4);
         } else {
             std::vector<float> o(n);
             for (int co = 0; co < Cout; ++co)
@@ -1467,6 +1540,9 @@ int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out
 }
 int rs_op_nhwc_to_nchw(const void* in, float* out, int B, int C, int HW, int in_prec, void* stream) {
     return rs_nhwc_to_nchw_launch(in, in_prec, out, B, C, HW, C, 0, (hipStream_t)stream);
+}
+int rs_op_convert(const void* src, int src_prec, void* dst, int dst_prec, int C, long long npix, void* stream) {
+    return rs_convert_launch(src, src_prec, dst, dst_prec, C, npix, (hipStream_t)stream);
 }
 
 }  // extern "C"

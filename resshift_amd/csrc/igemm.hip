@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 // y[m][n] = act(scale * sum_z partial[z][m][n] + bias[n]) + res[m][n]; fixed summation order -> deterministic
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
+    constexpr int PM = Store<TO>::PM;   // split storage: pixel record = 2 * ld halfs
     const long long nq = (long long)p.M * (p.Cout >> 2);  // quads of 4 channels (Cout % 4 == 0 is guaranteed by the planner)
     const long long slab = (long long)p.M * p.Cout;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
@@ -301,18 +302,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IGemmParams p) {
             v[r] = epi_act<TO>(t, p.act);
         }
         if (p.res) {
+            const TO* rp = (const TO*)p.res + m * p.ldres * PM + n;
             if ((p.ldres & 3) == 0) {
                 float rv[4];
-                Out4<TO>::load((const TO*)p.res + m * p.ldres + n, rv);
+                Out4<TO>::load(rp, rv, p.ldres);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += rv[r];
             } else {
-                for (int r = 0; r < 4; ++r) v[r] += (float)((const TO*)p.res)[m * p.ldres + n + r];
+                for (int r = 0; r < 4; ++r) v[r] += rs_ld<TO>(rp + r, p.ldres);
             }
         }
-        TO* yp = (TO*)p.y + m * p.ldy + n;
-        if ((p.ldy & 3) == 0) Out4<TO>::store(yp, v);
-        else for (int r = 0; r < 4; ++r) yp[r] = (TO)v[r];
+        TO* yp = (TO*)p.y + m * p.ldy * PM + n;
+        if ((p.ldy & 3) == 0) Out4<TO>::store(yp, v, p.ldy);
+        else for (int r = 0; r < 4; ++r) rs_st<TO>(yp + r, p.ldy, v[r]);
     }
 }
 
@@ -365,12 +367,15 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
 extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, int BP, int BC, int nz, hipStream_t st);
 extern "C" int rs_igemm3_pick(int M, int Cout, int Ktot, int in_dt, int nz, int splitk, int* BC);
 extern "C" int rs_igemm3_launch(const IGemmParams* pp, int out_dt, int BC, hipStream_t st);
+extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC);
+extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st);
 
 extern "C" int rs_splitk_reduce_launch(const IGemmParams* pp, int out_dt, hipStream_t st) {
     const IGemmParams& p = *pp;
     const long long nq = (long long)p.M * (p.Cout >> 2);
     const unsigned blocks = (unsigned)std::min<long long>((nq + 255) / 256, 4096);
     if (out_dt == RS_F16) hipLaunchKernelGGL((splitk_reduce_kernel<f16>), dim3(blocks), dim3(256), 0, st, p);
+    else if (out_dt == RS_F16S) hipLaunchKernelGGL((splitk_reduce_kernel<h2s>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -379,6 +384,15 @@ extern "C" int rs_splitk_reduce_launch(const IGemmParams* pp, int out_dt, hipStr
 // fp32 workspace of splitk * M * Cout floats (IGemmParams::partial).
 extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
     int BP, BC;
+    if (in_dt == RS_F16S) {   // split storage (igemm_split.hip): one workgroup per CU, so aim at one round of workgroups
+        rs_igemm_split_pick(M, Cout, 1, &BP, &BC);
+        const int tiles = ((M + BP - 1) / BP) * ((Cout + BC - 1) / BC);
+        const int nk = (Ktot + 63) / 64;
+        if (tiles >= 200 || nk < 16 || (Cout & 3)) return 1;
+        int s = std::min((256 + tiles - 1) / tiles, 16);
+        s = std::min(s, nk / 8);
+        return std::max(s, 1);
+    }
     pick_tile(M, Cout, BP, BC);
     if (Cout > 64) {          // igemm2 takes every single-source launch with more than 64 channels: ask it for its tile
         int bp2 = 0, bc2 = 0;
@@ -397,16 +411,17 @@ extern "C" int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt) {
     return std::max(s, 1);
 }
 
-// in_dt: storage type of x/w; out_dt: storage type of y/res.  Supported: (F16,F16) (F16,F32) (F32,F32).
+// in_dt: storage type of x/w; out_dt: storage type of y/res.  Supported: (F16,F16) (F16,F32) (F32,F32) (F16S,F16S) (F16S,F32).
 // Requirements: (C0+C1) and C0 multiples of the 16-byte chunk (8 halfs / 4 floats); ld0/ld1 likewise;
 // source base pointers 16-byte aligned.  p.splitk > 1 requires nz == 1 and p.partial.
 extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int nz, hipStream_t st) {
     IGemmParams p = *pp;
-    const int ch = in_dt == RS_F16 ? 8 : 4;
+    const int ch = in_dt == RS_F32 ? 4 : 8;
     if ((p.C0 % ch) || (p.C1 % ch) || (p.ld0 % ch) || (p.C1 && (p.ld1 % ch)) || p.M <= 0 || p.Cout <= 0) return -2;
     if (p.up != 1 && p.up != 2) return -2;
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
+    if (in_dt == RS_F16S) return rs_igemm_split_launch(&p, out_dt, nz, st);   // split storage: igemm_split.hip (single source)
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();
     int bp2 = 0, bc2 = 0;

@@ -68,22 +68,34 @@ template <> struct MfmaOps<float> {
     }
 };
 
-template <typename TO> struct Out4;
+template <typename TO> struct Out4;   // 4 consecutive output elements (`lo`: see h2s in common.h; ignored by the plain types)
+template <> struct Out4<h2s> {
+    static __device__ __forceinline__ void load(const h2s* p, float (&v)[4], int lo) {
+        const f16x4 h = *(const f16x4*)p, l = *(const f16x4*)((const f16*)p + lo);
+        v[0] = rs_join(h[0], l[0]); v[1] = rs_join(h[1], l[1]); v[2] = rs_join(h[2], l[2]); v[3] = rs_join(h[3], l[3]);
+    }
+    static __device__ __forceinline__ void store(h2s* p, const float (&v)[4], int lo) {
+        f16x4 h, l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { f16 a, b; rs_split(v[r], a, b); h[r] = a; l[r] = b; }
+        *(f16x4*)p = h; *(f16x4*)((f16*)p + lo) = l;
+    }
+};
 template <> struct Out4<f16> {
-    static __device__ __forceinline__ void load(const f16* p, float (&v)[4]) {
+    static __device__ __forceinline__ void load(const f16* p, float (&v)[4], int lo = 0) {
         f16x4 t = *(const f16x4*)p;
         v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
     }
-    static __device__ __forceinline__ void store(f16* p, const float (&v)[4]) {
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[4], int lo = 0) {
         f16x4 t; t[0] = (f16)v[0]; t[1] = (f16)v[1]; t[2] = (f16)v[2]; t[3] = (f16)v[3];
         *(f16x4*)p = t;
     }
 };
 template <> struct Out4<float> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4], int lo = 0) {
         f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     }
-    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4], int lo = 0) {
         f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
         *(f32x4*)p = t;
     }
@@ -91,8 +103,8 @@ template <> struct Out4<float> {
 
 // fp16-storage outputs use the v_rcp / v_exp formulations of common.h; the fp32 path keeps libm's erff and IEEE division
 template <typename TO> __device__ __forceinline__ float epi_act(float x, int act) {
-    if (act == RS_ACT_GELU) return sizeof(TO) == 2 ? rs_gelu_fast(x) : rs_gelu(x);
-    if (act == RS_ACT_SILU) return sizeof(TO) == 2 ? rs_silu_fast(x) : rs_silu(x);
+    if (act == RS_ACT_GELU) return Store<TO>::FAST ? rs_gelu_fast(x) : rs_gelu(x);
+    if (act == RS_ACT_SILU) return Store<TO>::FAST ? rs_silu_fast(x) : rs_silu(x);
     return x;
 }
 

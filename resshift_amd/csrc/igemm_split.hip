@@ -1,0 +1,501 @@
+// Implicit-GEMM kernel for SPLIT storage (RS_F16S, common.h): fp32-class convolutions / linears / batched GEMMs on the
+// fp16 matrix cores.  Both operands arrive as (hi, lo) fp16 pairs, x = hi + lo * 2^-11, and every product is formed as
+//     W.X = Wh.Xh  +  2^-11 (Wh.Xl + Wl.Xh)            (the dropped Wl.Xl term is <= 2^-24 |W.X|)
+// with three v_mfma_f32_16x16x32_f16 per fragment pair into two fp32 accumulators (main, cross): 1/3 of the fp16 matrix
+// rate, against 1/16 for the exact v_mfma_f32_16x16x4_f32 path - the precision policy that reproduces the reference's
+// VQ codes (ldm/modules/vqvae/quantize.py:276-285) without paying for exact fp32 MFMAs.
+//
+// Same formulation, operand gather, swizzled LDS image and LDS-DMA ring as igemm2.hip (see there), with
+//   * a K stage = 128 bytes of hi AND 128 bytes of lo per row: LDS slot = [X hi | W hi | X lo | W lo], two LDS-DMA
+//     instructions per row round; pixel records in HBM are [ld halfs hi | ld halfs lo], weight rows [K hi | K lo];
+//   * a 2-slot ring, one workgroup per CU (<= 160 KB of LDS, <= 256 VGPRs): 128 pixels x BC in {64,128,160,192} on 8
+//     waves, or 64 pixels x BC on 4 waves for the launches that cannot fill the chip (split-K, 16x16 / 8x8 UNet levels);
+//   * epilogue in exact fp32 arithmetic (IEEE division, libm erff): main + 2^-11 cross, scale, bias, activation,
+//     residual (split storage), then either fp32 output or a fresh (hi, lo) split, transposed through LDS into 16-byte
+//     stores.
+#include "igemm_common.h"
+#include <algorithm>
+#include <type_traits>
+
+extern "C" int rs_splitk_reduce_launch(const IGemmParams* p, int out_dt, hipStream_t st);
+
+namespace {
+
+using namespace igemm_detail;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// NB: keep the LDS-DMA builtin inside a plain __device__ function (see igemm2.hip)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL (builds with -DRS_SPLIT_ABLATE only): timing ablations of the K loop, results wrong: 1 = no refill loads after the
+// prologue, 2 = no ds_read / MFMA, 4 = no barrier (compile-time: runtime switches in the loop cost registers)
+template <typename TO, int BP, int BC, int NWV, bool PIPE, int ABL = 0>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel(IGemmParams p) {
+    constexpr int WPN = NWV / 2;               // pixel-waves (x 2 channel-waves)
+    constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
+    constexpr int BK = 64;                     // halfs of K per stage (128 bytes of hi + 128 bytes of lo per row)
+    constexpr int RWP = BC % RND;              // rows of the partial weight round (whole waves: a multiple of 8)
+    static_assert(RWP % 8 == 0, "partial round must be whole waves");
+    constexpr int RX = BP / RND, RW = (BC + RND - 1) / RND;
+    constexpr int L = 2 * (RX + RW);           // LDS-DMA instructions per thread per stage (hi + lo)
+    constexpr int FP = BP / WPN / 16;          // wave tile = (BP/WPN) pixels x (BC/2) channels
+    constexpr int FC = BC / 32;
+    constexpr int PLANE = (BP + BC) * 128;     // [X rows | W rows] of one half (hi or lo)
+    constexpr int STAGE = 2 * PLANE;
+    static_assert(BP % RND == 0 && (BP / WPN) % 16 == 0 && BC % 32 == 0 && 2 * STAGE <= 160 * 1024, "tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wp = wave % WPN, wc = wave / WPN;
+    const int rr = 8 * wave + (lane >> 3);             // row inside a load round
+    const int kcp = (lane & 7) ^ ((lane >> 3) & 7);    // source K-chunk of this lane (swizzle on the source side)
+    const bool wpart = !RWP || wave < RWP / 8;         // this wave owns rows of the last (partial) weight round
+
+    const int nby = (p.Cout + BC - 1) / BC;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / nby) * BP;
+    const int n0 = (tile % nby) * BC;
+    const long long z = blockIdx.z;
+    const bool split = p.splitk > 1;
+
+    constexpr unsigned INV = 0xF0000000u;   // beyond num_records: the hardware returns zeros
+    const f16* x0 = (const f16*)p.x0 + (split ? 0 : 2 * z * p.bs_x0);
+    const f16* w = (const f16*)p.w + (split ? 0 : 2 * z * p.bs_w);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, p.w_bytes, 0x00020000);
+
+    const int Ctot = p.C0;
+    const int ntaps = p.KH * p.KW;
+    const int Hv = p.Hs * p.up, Wv = p.Ws * p.up;
+    const int ush = p.up == 2 ? 1 : 0;
+    const int HoWo = p.Ho * p.Wo;
+    const unsigned xlo = (unsigned)p.ld0 * 2u;     // byte distance hi -> lo inside a pixel record
+    const unsigned wlo = (unsigned)p.Ktot * 2u;    // ... inside a weight row
+
+    int pixbase[RX], iy0[RX], ix0[RX];
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int m = m0 + RND * i + rr;
+        if (m < p.M) {
+            int b, rem, oy, ox;
+            if (p.sh_wo >= 0) {
+                b = m >> p.sh_howo; rem = m & (HoWo - 1); oy = rem >> p.sh_wo; ox = rem & (p.Wo - 1);
+            } else {
+                b = m / HoWo; rem = m - b * HoWo; oy = rem / p.Wo; ox = rem - oy * p.Wo;
+            }
+            pixbase[i] = b * p.Hs * p.Ws;
+            iy0[i] = oy * p.stride - p.pad_t;
+            ix0[i] = ox * p.stride - p.pad_l;
+        } else {
+            pixbase[i] = -1; iy0[i] = 0; ix0[i] = 0;
+        }
+    }
+    unsigned woff[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int n = n0 + RND * i + rr;
+        woff[i] = (RND * i + rr < BC && n < p.Cout) ? (unsigned)n * (unsigned)p.Ktot * 4u : INV;
+    }
+    const int nk_total = (p.Ktot + BK - 1) / BK;
+    int kt0 = 0, nk = nk_total;
+    if (split) {
+        const int per = (nk_total + p.splitk - 1) / p.splitk;
+        kt0 = min(nk_total, (int)z * per);
+        nk = min(nk_total, kt0 + per) - kt0;
+    }
+    int kk = kt0 * BK + kcp * 8;
+    int tap = kk / Ctot;
+    int cc = kk - tap * Ctot;
+
+    unsigned off[RX];
+    int ky = tap / p.KW, kx = tap - ky * p.KW;
+    auto set_tap = [&]() {
+        const bool kvalid = tap < ntaps;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool ok = kvalid && pixbase[i] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            const unsigned pix = (unsigned)(pixbase[i] + (iy >> ush) * p.Ws + (ix >> ush));
+            off[i] = ok ? pix * (unsigned)p.ld0 * 4u : INV;
+        }
+    };
+    set_tap();
+
+    auto issue = [&](int slot) {
+        char* sbase = smem + slot * STAGE + (8 * wave) * 128;   // wave-uniform
+        const unsigned cb = (unsigned)cc * 2u;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            lds_dma16(rx, sbase + (RND * i) * 128, off[i] + cb);
+            lds_dma16(rx, sbase + PLANE + (RND * i) * 128, off[i] == INV ? INV : off[i] + cb + xlo);
+        }
+        const bool wk = kk < p.Ktot;
+        const unsigned kb = (unsigned)kk * 2u;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            if (RWP && i == RW - 1 && !wpart) continue;   // wave-uniform: this wave's rows of the last round are >= BC
+            const bool ok = wk && woff[i] != INV;
+            lds_dma16(rw, sbase + (BP + RND * i) * 128, ok ? woff[i] + kb : INV);
+            lds_dma16(rw, sbase + PLANE + (BP + RND * i) * 128, ok ? woff[i] + kb + wlo : INV);
+        }
+        kk += BK;
+        cc += BK;
+        if (cc >= Ctot) {
+            do {
+                cc -= Ctot; ++tap;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            } while (cc >= Ctot);
+            set_tap();
+        }
+    };
+
+    const int swz0 = ((lg ^ (lr & 7)) << 4), swz1 = (((4 + lg) ^ (lr & 7)) << 4);
+    const int la = BP * 128 + (wc * (BC / 2) + lr) * 128, lb = (wp * (BP / WPN) + lr) * 128;
+
+    f32x4 am[FC][FP], ac[FC][FP];   // main (hi.hi) and cross (hi.lo + lo.hi, scaled by 2^11) accumulators
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) { am[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if constexpr (!PIPE) {
+        // reference schedule (RS_SPLIT_PIPE=0, for A/B runs): the whole refill is issued right behind the barrier
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 0 && nk > 1) {   // stage 1 was issued with stage 0; its loads (two fewer on the waves that skip the partial round) may fly on
+                if (RWP && !wpart) wait_vmcnt<L - 2>(); else wait_vmcnt<L>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt >= 1 && kt + 1 < nk) issue((kt + 1) & 1);   // refill the slot every wave finished reading before this barrier
+            const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = ks ? swz1 : swz0;
+                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    ah[i] = *(const f16x8*)(sb + la + sw + i * 2048);
+                    al[i] = *(const f16x8*)(sb + PLANE + la + sw + i * 2048);
+                }
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    bh[j] = *(const f16x8*)(sb + lb + sw + j * 2048);
+                    bl[j] = *(const f16x8*)(sb + PLANE + lb + sw + j * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) am[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], ac[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], ac[i][j], 0, 0, 0);
+            }
+        }
+    } else {
+        // Pipelined schedule.  A stage is 2 * FC blocks of 3 * FP MFMAs (one channel fragment of one k-step each).  The L
+        // LDS-DMA instructions of the refill are NOT issued in one burst behind the barrier - every wave would sit in the
+        // texture-address queue for ~L KB / (52 B/clk) while the matrix pipe idles - but one or two per block, in front of
+        // that block's MFMAs, over the first DBLK blocks (the rest of the stage gives the last pieces time to land before
+        // the next barrier's vmcnt(0)).  The fragments of k-step 1 are read into a second register set while k-step 0
+        // computes.  sched_barrier(0) pins the block order; inside a block the compiler schedules freely.
+        constexpr int NBLK = 2 * FC;
+        constexpr int DBLK = NBLK - (NBLK >= 8 ? 3 : 1);            // blocks that carry DMA pieces
+        constexpr bool DBUF = (FC + FP) * 16 + FC * FP * 8 <= 200;  // second fragment set only where it fits 256 VGPRs
+        // piece d of the refill: d < 2 RX -> pixel rows (round d/2, half d&1), then weight rows
+        auto piece = [&](char* sbase, unsigned cb, unsigned kb, bool wk, int d) {
+            if (d < 2 * RX) {
+                const int i = d >> 1, half = d & 1;
+                lds_dma16(rx, sbase + half * PLANE + (RND * i) * 128, off[i] == INV ? INV : off[i] + cb + (half ? xlo : 0u));
+            } else {
+                const int e = d - 2 * RX, i = e >> 1, half = e & 1;
+                if (RWP && i == RW - 1 && !wpart) return;
+                const bool ok = wk && woff[i] != INV;
+                lds_dma16(rw, sbase + half * PLANE + (BP + RND * i) * 128, ok ? woff[i] + kb + (half ? wlo : 0u) : INV);
+            }
+        };
+        auto stage = [&](int kt, auto refill_tag, auto compute_tag) {
+            constexpr bool REFILL = decltype(refill_tag)::value;
+            constexpr bool COMPUTE = decltype(compute_tag)::value;   // false: timing ablation (RS_IGEMM_DBG & 2), results wrong
+            const char* sb = smem + (kt & 1) * STAGE;
+            char* sbase = smem + ((kt + 1) & 1) * STAGE + (8 * wave) * 128;
+            const unsigned cb = (unsigned)cc * 2u, kb = (unsigned)kk * 2u;
+            const bool wk = kk < p.Ktot;
+            f16x8 ah[2][FC], al[2][FC], bh[2][FP], bl[2][FP];
+            auto read_set = [&](int ks, int set) {
+                const int sw = ks ? swz1 : swz0;
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    bh[set][j] = *(const f16x8*)(sb + lb + sw + j * 2048);
+                    bl[set][j] = *(const f16x8*)(sb + PLANE + lb + sw + j * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    ah[set][i] = *(const f16x8*)(sb + la + sw + i * 2048);
+                    al[set][i] = *(const f16x8*)(sb + PLANE + la + sw + i * 2048);
+                }
+            };
+            if (COMPUTE) read_set(0, 0);
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const int ks = blk / FC, i = blk % FC;
+                const int set = DBUF ? ks : 0;
+                if (REFILL) {
+#pragma unroll
+                    for (int d = 0; d < L; ++d)
+                        if (d * DBLK / L == blk) piece(sbase, cb, kb, wk, d);
+                }
+                if (COMPUTE) {
+                    if (DBUF ? blk == 1 : blk == FC) read_set(1, DBUF ? 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) am[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][i], bh[set][j], am[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][i], bl[set][j], ac[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[set][i], bh[set][j], ac[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (REFILL) {   // step this lane's K cursor past the stage just requested
+                kk += BK;
+                cc += BK;
+                if (cc >= Ctot) {
+                    do {
+                        cc -= Ctot; ++tap;
+                        if (++kx == p.KW) { kx = 0; ++ky; }
+                    } while (cc >= Ctot);
+                    set_tap();
+                }
+            }
+        };
+        if (nk > 0) {
+            if (nk > 1) { if (RWP && !wpart) wait_vmcnt<L - 2>(); else wait_vmcnt<L>(); } else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            stage(0, std::false_type{}, std::true_type{});
+        }
+        for (int kt = 1; kt + 1 < nk; ++kt) {
+            wait_vmcnt<0>();
+            if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+            stage(kt, std::integral_constant<bool, !(ABL & 1)>{}, std::integral_constant<bool, !(ABL & 2)>{});
+        }
+        if (nk > 1) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            stage(nk - 1, std::false_type{}, std::true_type{});
+        }
+    }
+    __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
+
+    // ---------------------------------------------------------------- epilogue
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) am[i][j][r] = fmaf(ac[i][j][r], RS_LO_INV, am[i][j][r]);
+
+    if (split) {
+        float* part = p.partial + z * (long long)p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (n >= p.Cout) continue;
+                float* pp = part + (long long)m * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) *(f32x4*)pp = am[i][j];
+                else for (int r = 0; r < 4 && n + r < p.Cout; ++r) pp[r] = am[i][j][r];
+            }
+        }
+        return;
+    }
+    const f16* res = p.res ? (const f16*)p.res + 2 * z * p.bs_res : nullptr;   // residual: split storage, pixel stride ldres
+    const bool quad = (p.Cout & 3) == 0 && (p.ldres & 3) == 0;
+    // scale, bias, activation, residual of one fragment, in place
+    auto finish = [&](int i, int j) {
+        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+        const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = am[i][j][r] * p.out_scale;
+            if (p.bias && n + r < p.Cout) t += p.bias[n + r];
+            v[r] = p.act == RS_ACT_GELU ? rs_gelu(t) : (p.act == RS_ACT_SILU ? rs_silu(t) : t);
+        }
+        if (res && m < p.M && n < p.Cout) {
+            const f16* rp = res + (long long)m * p.ldres * 2 + n;
+            if (quad && n + 3 < p.Cout) {
+                const f16x4 rh = *(const f16x4*)rp, rl = *(const f16x4*)(rp + p.ldres);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[r], rl[r]);
+            } else {
+                for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += rs_join(rp[r], rp[p.ldres + r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) am[i][j][r] = v[r];
+    };
+    if constexpr (std::is_same<TO, h2s>::value) {
+        f16* y = (f16*)p.y + 2 * z * p.bs_y;
+        // wave tile (BP/WPN rows x BC/2 channels) staged twice (hi, lo) with a padded row pitch, then 16-byte stores
+        constexpr int ROWB = (BC / 2) * 2 + 16;
+        constexpr int WTILE = (BP / WPN) * ROWB;
+        char* stg = smem + wave * 2 * WTILE;
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                finish(i, j);
+                f16x4 h, l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f16 a, b; rs_split(am[i][j][r], a, b); h[r] = a; l[r] = b; }
+                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                *(f16x4*)(stg + WTILE + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = l;
+            }
+        __syncthreads();
+        constexpr int CPR = (BC / 2) / 8;
+        constexpr int NITEM = (BP / WPN) * CPR;
+        const bool vec_ok = (p.ldy & 7) == 0;
+        for (int idx = lane; idx < 2 * NITEM; idx += 64) {
+            const int half = idx >= NITEM ? 1 : 0;
+            const int it = idx - half * NITEM;
+            const int row = it / CPR, c8 = it - row * CPR;
+            const int m = m0 + wp * (BP / WPN) + row;
+            const int n = n0 + wc * (BC / 2) + c8 * 8;
+            if (m >= p.M || n >= p.Cout) continue;
+            const uint4 v = *(const uint4*)(stg + half * WTILE + row * ROWB + c8 * 16);
+            f16* yp = y + (long long)m * p.ldy * 2 + half * p.ldy + n;
+            if (vec_ok && n + 7 < p.Cout) {
+                *(uint4*)yp = v;
+            } else {
+                const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (n + r < p.Cout) yp[r] = hv[r];
+            }
+        }
+    } else {
+        float* y = (float*)p.y + z * p.bs_y;
+        const bool vec_ok = ((p.ldy & 3) == 0);
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (m >= p.M || n >= p.Cout) continue;
+                finish(i, j);
+                float* yp = y + (long long)m * p.ldy + n;
+                if (n + 3 < p.Cout && vec_ok) *(f32x4*)yp = am[i][j];
+                else for (int r = 0; r < 4 && n + r < p.Cout; ++r) yp[r] = am[i][j][r];
+            }
+        }
+    }
+}
+
+template <typename TO, int BP, int BC, int NWV, bool PIPE, int ABL = 0>
+hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
+    const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
+    constexpr size_t lds = (size_t)2 * 2 * (BP + BC) * 128;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_split_kernel<TO, BP, BC, NWV, PIPE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * 4, wb = (size_t)p.Cout * p.Ktot * 4;
+    if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+    {
+        const int howo = p.Ho * p.Wo;
+        const bool pow2 = howo > 0 && (howo & (howo - 1)) == 0 && (p.Wo & (p.Wo - 1)) == 0;
+        p.sh_howo = pow2 ? __builtin_ctz(howo) : -1;
+        p.sh_wo = pow2 ? __builtin_ctz(p.Wo) : -1;
+    }
+    hipLaunchKernelGGL((igemm_split_kernel<TO, BP, BC, NWV, PIPE, ABL>), dim3(tiles, 1, p.splitk > 1 ? p.splitk : nz), dim3(64 * NWV), lds, st, p);
+    if (p.splitk > 1 && rs_splitk_reduce_launch(&p, std::is_same<TO, h2s>::value ? RS_F16S : RS_F32, st) != 0) return hipErrorLaunchFailure;
+    return hipGetLastError();
+}
+
+template <typename TO, int BP, int BC, int NWV>
+hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
+    static const bool pipe = []() { const char* e = getenv("RS_SPLIT_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+#ifdef RS_SPLIT_ABLATE
+    if constexpr (std::is_same<TO, h2s>::value && NWV == 8) {
+        static const int abl = []() { const char* e = getenv("RS_IGEMM_DBG"); return e ? atoi(e) : 0; }();
+        switch (abl) {
+            case 1: return launch_cfg2<TO, BP, BC, NWV, true, 1>(p, nz, st);
+            case 2: return launch_cfg2<TO, BP, BC, NWV, true, 2>(p, nz, st);
+            case 4: return launch_cfg2<TO, BP, BC, NWV, true, 4>(p, nz, st);
+            case 6: return launch_cfg2<TO, BP, BC, NWV, true, 6>(p, nz, st);
+            default: break;
+        }
+    }
+#endif
+    return pipe ? launch_cfg2<TO, BP, BC, NWV, true>(p, nz, st) : launch_cfg2<TO, BP, BC, NWV, false>(p, nz, st);
+}
+
+template <typename TO>
+hipError_t launch_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t st) {
+    if (BP == 64) {
+        switch (BC) {
+            case 64: return launch_cfg<TO, 64, 64, 4>(p, nz, st);
+            case 160: return launch_cfg<TO, 64, 160, 4>(p, nz, st);
+            case 192: return launch_cfg<TO, 64, 192, 4>(p, nz, st);
+            default: return launch_cfg<TO, 64, 128, 4>(p, nz, st);
+        }
+    }
+    switch (BC) {
+        case 64: return launch_cfg<TO, 128, 64, 8>(p, nz, st);
+        case 160: return launch_cfg<TO, 128, 160, 8>(p, nz, st);
+        case 192: return launch_cfg<TO, 128, 192, 8>(p, nz, st);
+        default: return launch_cfg<TO, 128, 128, 8>(p, nz, st);
+    }
+}
+
+}  // namespace
+
+// tile choice: channel tile with the least padding (64 for the 3-channel heads), 64-pixel tiles on 4 waves where 128-pixel
+// tiles would leave most CUs idle (the 16x16 / 8x8 UNet levels at batch 32: M <= 8192)
+extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC) {
+    auto waste = [&](int bc) { return ((Cout + bc - 1) / bc) * bc - Cout; };
+    int best = 128, bw = waste(128);
+    if (waste(160) < bw) { best = 160; bw = waste(160); }
+    if (waste(192) < bw) { best = 192; bw = waste(192); }
+    if (Cout <= 64) best = 64;
+    *BC = best;
+    const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + best - 1) / best) * nz;
+    *BP = (tiles128 < 256) ? 64 : 128;
+}
+
+// in: split storage; out_dt: RS_F16S or RS_F32.  Single source only (C1 == 0), C0 / ld0 / Ktot multiples of 8.
+extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st) {
+    const IGemmParams& p = *pp;
+    if (p.C1 != 0 || (p.C0 % 8) || (p.ld0 % 8) || (p.Ktot % 8)) return -2;
+    int BP, BC;
+    rs_igemm_split_pick(p.M, p.Cout, nz, &BP, &BC);   // (same arguments as the split-K planner: identical tile choice)
+    hipError_t e;
+    if (out_dt == RS_F16S) e = launch_t<h2s>(p, BP, BC, nz, st);
+    else if (out_dt == RS_F32) e = launch_t<float>(p, BP, BC, nz, st);
+    else return -2;
+    return e == hipSuccess ? 0 : -1;
+}

@@ -29,15 +29,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
     if (pp < PP) {
-        const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + j * 8;
+        const long long rx = (long long)p.ldx * Store<T>::PM;   // pixel record length (split storage: hi + lo)
+        const T* x = (const T*)p.x + ((long long)b * p.HW) * rx + j * 8;
         // 4 independent 16-byte loads in flight per thread (the loop is latency-, not bandwidth-bound otherwise)
         int pix = p0 + pp;
         for (; pix + 3 * PP < p1; pix += 4 * PP) {
             Vec8<T> v0, v1, v2, v3;
-            v0.load(x + (long long)pix * p.ldx);
-            v1.load(x + (long long)(pix + PP) * p.ldx);
-            v2.load(x + (long long)(pix + 2 * PP) * p.ldx);
-            v3.load(x + (long long)(pix + 3 * PP) * p.ldx);
+            v0.load(x + (long long)pix * rx, p.ldx);
+            v1.load(x + (long long)(pix + PP) * rx, p.ldx);
+            v2.load(x + (long long)(pix + 2 * PP) * rx, p.ldx);
+            v3.load(x + (long long)(pix + 3 * PP) * rx, p.ldx);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f0 = v0.get(e), f1 = v1.get(e), f2 = v2.get(e), f3 = v3.get(e);
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
         }
         for (; pix < p1; pix += PP) {
             Vec8<T> v;
-            v.load(x + (long long)pix * p.ldx);
+            v.load(x + (long long)pix * rx, p.ldx);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = v.get(e); sum[e] += f; sq[e] = fmaf(f, f, sq[e]); }
         }
@@ -74,12 +75,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
 // loads in flight per thread.  ACT is compile-time (no per-element branches); fp16 storage uses the v_rcp/v_exp SiLU.
 template <typename T, int ACT>
 __device__ __forceinline__ void gn_apply_rows(const GNParams& p, const float* ca, const float* cb, int b) {
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = Store<T>::FAST;
     const int nchunk = p.C >> 3;
     const int PP = 256 / nchunk;
     const int tid = threadIdx.x;
     const int j = tid % nchunk, pp = tid / nchunk;
     if (pp >= PP) return;
+    const long long rx = (long long)p.ldx * Store<T>::PM, ry = (long long)p.ldy * Store<T>::PM;
     float a[8], c[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = ca[j * 8 + e]; c[e] = cb[j * 8 + e]; }
@@ -87,27 +89,27 @@ __device__ __forceinline__ void gn_apply_rows(const GNParams& p, const float* ca
     const int pps = (p.HW + nslab - 1) / nslab;
     const int p0 = blockIdx.x * pps;
     const int p1 = min(p.HW, p0 + pps);
-    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + j * 8;
-    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy + j * 8;
+    const T* x = (const T*)p.x + ((long long)b * p.HW) * rx + j * 8;
+    T* y = (T*)p.y + ((long long)b * p.HW) * ry + j * 8;
     int pix = p0 + pp;
     for (; pix + 3 * PP < p1; pix += 4 * PP) {
         Vec8<T> v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u].load(x + (long long)(pix + u * PP) * p.ldx);
+        for (int u = 0; u < 4; ++u) v[u].load(x + (long long)(pix + u * PP) * rx, p.ldx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             Vec8<T> o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v[u].get(e), a[e], c[e])));
-            o.store(y + (long long)(pix + u * PP) * p.ldy);
+            o.store(y + (long long)(pix + u * PP) * ry, p.ldy);
         }
     }
     for (; pix < p1; pix += PP) {
         Vec8<T> v, o;
-        v.load(x + (long long)pix * p.ldx);
+        v.load(x + (long long)pix * rx, p.ldx);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v.get(e), a[e], c[e])));
-        o.store(y + (long long)pix * p.ldy);
+        o.store(y + (long long)pix * ry, p.ldy);
     }
 }
 
@@ -173,15 +175,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
 // instead of stats + apply.  Thread (pp, j) owns chunk j of the slice for pixels pp, pp+PP, ...
 template <typename T, int ACT, int MAXI, int NT>
 __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (*red)[17], float* ca, float* cb) {
-    constexpr bool FAST = sizeof(T) == 2;
+    constexpr bool FAST = Store<T>::FAST;
+    const long long rx = (long long)p.ldx * Store<T>::PM, ry = (long long)p.ldy * Store<T>::PM;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups;
     const int nch = SC >> 3, PP = NT / nch;
     const int j = tid % nch, pp = tid / nch;
     const int cs = blockIdx.x * SC;               // first channel of the slice
     const bool active = pp < PP;
-    const T* x = (const T*)p.x + ((long long)b * p.HW) * p.ldx + cs + j * 8;
-    T* y = (T*)p.y + ((long long)b * p.HW) * p.ldy + cs + j * 8;
+    const T* x = (const T*)p.x + ((long long)b * p.HW) * rx + cs + j * 8;
+    T* y = (T*)p.y + ((long long)b * p.HW) * ry + cs + j * 8;
     Vec8<T> v[MAXI];
     float sum[8], sq[8];
 #pragma unroll
@@ -189,7 +192,7 @@ __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
         const int pix = pp + k * PP;
-        if (active && pix < p.HW) v[k].load(x + (long long)pix * p.ldx);
+        if (active && pix < p.HW) v[k].load(x + (long long)pix * rx, p.ldx);
     }
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
@@ -253,7 +256,7 @@ __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (
             Vec8<T> o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.set(e, rs_act_t<ACT, FAST>(fmaf(v[k].get(e), a[e], c[e])));
-            o.store(y + (long long)pix * p.ldy);
+            o.store(y + (long long)pix * ry, p.ldy);
         }
     }
 }
@@ -301,6 +304,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
         if (SC > 0) {
             dim3 g(p.C / SC, p.B);
             if (dt == RS_F16) hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI, 256>), g, dim3(256), 0, st, p, SC);
+            else if (dt == RS_F16S) hipLaunchKernelGGL((gn_fused_kernel<h2s, MAXI, 256>), g, dim3(256), 0, st, p, SC);
             else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI, 256>), g, dim3(256), 0, st, p, SC);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
@@ -318,6 +322,9 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     if (dt == RS_F16) {
         hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
+    } else if (dt == RS_F16S) {
+        hipLaunchKernelGGL((gn_stats_kernel<h2s>), g1, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gn_apply_kernel<h2s>), g2, dim3(256), lds, st, p);
     } else {
         hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), lds, st, p);
@@ -350,14 +357,14 @@ __global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
     int sy = ys + p.shift; if (sy >= p.H) sy -= p.H;
     int sx = xs + p.shift; if (sx >= p.W) sx -= p.W;
     const long long pix = ((long long)b * p.H + sy) * p.W + sx;
-    const T* src = (const T*)p.qkv + pix * p.ldq + h * HD;
+    const T* src = (const T*)p.qkv + pix * p.ldq * Store<T>::PM + h * HD;
     float q[HD];
 #pragma unroll
     for (int c = 0; c < HD; c += 8) {
         Vec8<T> vq, vk, vv;
-        vq.load(src + c);
-        vk.load(src + E + c);
-        vv.load(src + 2 * E + c);
+        vq.load(src + c, p.ldq);
+        vk.load(src + E + c, p.ldq);
+        vv.load(src + 2 * E + c, p.ldq);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             q[c + e] = vq.get(e) * p.scale;
@@ -420,13 +427,13 @@ __global__ __launch_bounds__(512) void win_attn_kernel(WinAttnParams p) {
         }
     }
     // window_reverse + reverse roll: the result goes back to the pixel the token was read from
-    T* dst = (T*)p.out + pix * p.ldo + h * HD;
+    T* dst = (T*)p.out + pix * p.ldo * Store<T>::PM + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 8) {
         Vec8<T> ov;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ov.set(e, o[c + e]);
-        ov.store(dst + c);
+        ov.store(dst + c, p.ldo);
     }
 }
 
@@ -559,6 +566,153 @@ __global__ __launch_bounds__(512) void win_attn_mfma_kernel(WinAttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
             *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+        }
+}
+
+}  // namespace
+
+namespace {
+
+// Split-storage window attention on the matrix cores (RS_F16S): the structure of win_attn_mfma_kernel with every product
+// formed from (hi, lo) fp16 pairs - S^T = Kh Qh^T + 2^-11 (Kh Ql^T + Kl Qh^T), O^T likewise with P split on the fly - so
+// the attention core stays fp32-class like the split implicit GEMM around it (3 MFMAs per product, two accumulators).
+__global__ __launch_bounds__(512) void win_attn_split_kernel(WinAttnParams p) {
+    constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8;  // V^T row pitch in halfs (144 B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+    f16* vth = (f16*)smem + (size_t)h * 2 * HD * VP;  // [HD][VP] hi, then [HD][VP] lo of this head
+    f16* vtl = vth + HD * VP;
+    const int nwx = p.W / WS;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    const int b = blockIdx.y;
+    const int E = p.heads * HD;
+    const f16* qkv = (const f16*)p.qkv;
+    const long long rq = 2LL * p.ldq;     // pixel record: [ldq hi | ldq lo]
+    auto pixel = [&](int t) -> long long {
+        int sy = wy * WS + (t >> 3) + p.shift; if (sy >= p.H) sy -= p.H;
+        int sx = wx * WS + (t & 7) + p.shift; if (sx >= p.W) sx -= p.W;
+        return ((long long)b * p.H + sy) * p.W + sx;
+    };
+    {   // V^T staging: lane = token
+        const f16* vsrc = qkv + pixel(lane) * rq + 2 * E + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const f16x8 vh = *(const f16x8*)(vsrc + 8 * c), vl = *(const f16x8*)(vsrc + p.ldq + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vth[(8 * c + e) * VP + lane] = vh[e]; vtl[(8 * c + e) * VP + lane] = vl[e]; }
+        }
+    }
+    long long pix[4];
+    f16x8 kh[4], kl[4], qh[4], ql[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        pix[f] = pixel(16 * f + lr);
+        const f16* src = qkv + pix[f] * rq + h * HD + 8 * lg;
+        qh[f] = *(const f16x8*)src;           ql[f] = *(const f16x8*)(src + p.ldq);
+        kh[f] = *(const f16x8*)(src + E);     kl[f] = *(const f16x8*)(src + E + p.ldq);
+    }
+    f32x4 s[4][4];  // [fj][fi]
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[fj], ql[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[fj], qh[fi], c, 0, 0, 0);
+            const f32x4 m = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[fj], qh[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[fj][fi][r] = fmaf(c[r], RS_LO_INV, m[r]);
+        }
+    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+    if (p.shift > 0) {   // region ids of the (quirky) shift mask: band of window_row*8 + token_column (see win_attn_kernel)
+        auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
+        rid_i = band(lr & 7);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
+    }
+    float inv[4];
+    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+        const int i = 16 * fi + lr;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
+                s[fj][fi][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(s[fj][fi][r] - m);
+                s[fj][fi][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[fi] = 1.0f / l;
+    }
+    __syncthreads();  // V^T of every head is in LDS
+    f32x4 om[2][4], oc[2][4];    // [fd][fi] main / cross
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) { om[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 vah[2], val[2], pbh[4], pbl[4];
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            const int o = (16 * fd + lr) * VP + 32 * ks + 4 * lg;
+            const f16x4 a0 = *(const f16x4*)(vth + o), a1 = *(const f16x4*)(vth + o + 16);
+            const f16x4 b0 = *(const f16x4*)(vtl + o), b1 = *(const f16x4*)(vtl + o + 16);
+            vah[fd] = f16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            val[fd] = f16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, bq;
+                rs_split(s[2 * ks][fi][r], a, bq);     pbh[fi][r] = a;     pbl[fi][r] = bq;
+                rs_split(s[2 * ks + 1][fi][r], a, bq); pbh[fi][4 + r] = a; pbl[fi][4 + r] = bq;
+            }
+        }
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                om[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[fd], pbh[fi], om[fd][fi], 0, 0, 0);
+                oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[fd], pbl[fi], oc[fd][fi], 0, 0, 0);
+                oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val[fd], pbh[fi], oc[fd][fi], 0, 0, 0);
+            }
+    }
+    f16* out = (f16*)p.out;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            f16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, bq;
+                rs_split(fmaf(oc[fd][fi][r], RS_LO_INV, om[fd][fi][r]) * inv[fi], a, bq);
+                hv[r] = a; lv[r] = bq;
+            }
+            f16* dst = out + pix[fi] * 2 * p.ldo + h * HD + 16 * fd + 4 * lg;
+            *(f16x4*)dst = hv;
+            *(f16x4*)(dst + p.ldo) = lv;
         }
 }
 
@@ -848,6 +1002,15 @@ extern "C" int rs_win_attn_launch(const WinAttnParams* pp, int dt, hipStream_t s
     if (dt == RS_F16) {
         (void)hipFuncSetAttribute((const void*)win_attn_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((win_attn_kernel<f16>), grid, block, lds, st, p);
+    } else if (dt == RS_F16S) {
+        static const bool valu = []() { const char* e = getenv("RS_ATTN_SPLIT_VALU"); return e && e[0] == '1'; }();   // A/B knob: fp32 VALU kernel
+        if (p.bias_n && !valu) {
+            const size_t lds_m = (size_t)p.heads * 2 * 32 * (64 + 8) * sizeof(f16);
+            hipLaunchKernelGGL(win_attn_split_kernel, grid, block, lds_m, st, p);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        (void)hipFuncSetAttribute((const void*)win_attn_kernel<h2s>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((win_attn_kernel<h2s>), grid, block, lds, st, p);
     } else {
         (void)hipFuncSetAttribute((const void*)win_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((win_attn_kernel<float>), grid, block, lds, st, p);
@@ -877,7 +1040,7 @@ template <typename TO>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, TO* out, int ncols, long long lds_, long long ldo) {
     __shared__ float sh[4];
     const float* row = s + (long long)blockIdx.x * lds_;
-    TO* orow = out + (long long)blockIdx.x * ldo;
+    TO* orow = out + (long long)blockIdx.x * ldo * Store<TO>::PM;
     float mx = -3.0e38f;
     for (int c = threadIdx.x * 4; c < ncols; c += 1024) {
         const f32x4 v = *(const f32x4*)(row + c);
@@ -893,10 +1056,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, TO* o
     const float inv = 1.0f / sum;
     for (int c = threadIdx.x * 4; c < ncols; c += 1024) {
         const f32x4 v = *(const f32x4*)(row + c);
-        orow[c + 0] = (TO)(expf(v[0] - mx) * inv);
-        orow[c + 1] = (TO)(expf(v[1] - mx) * inv);
-        orow[c + 2] = (TO)(expf(v[2] - mx) * inv);
-        orow[c + 3] = (TO)(expf(v[3] - mx) * inv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs_st<TO>(orow + c + r, (int)ldo, expf(v[r] - mx) * inv);
     }
 }
 
@@ -907,6 +1068,8 @@ extern "C" int rs_softmax_rows_launch(const float* s, void* out, int out_dt, lon
     if (ncols % 4) return -2;
     if (out_dt == RS_F16)
         hipLaunchKernelGGL((softmax_rows_kernel<f16>), dim3((unsigned)nrows), dim3(256), 0, st, s, (f16*)out, ncols, lds_, ldo);
+    else if (out_dt == RS_F16S)
+        hipLaunchKernelGGL((softmax_rows_kernel<h2s>), dim3((unsigned)nrows), dim3(256), 0, st, s, (h2s*)out, ncols, lds_, ldo);
     else
         hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3((unsigned)nrows), dim3(256), 0, st, s, (float*)out, ncols, lds_, ldo);
     return hipGetLastError() == hipSuccess ? 0 : -1;

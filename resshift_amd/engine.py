@@ -13,8 +13,10 @@ import torch
 from . import _lib
 from .spec import _listify, unet_heads
 
-F16, F32 = _lib.RS_PREC_F16, _lib.RS_PREC_F32
-PRECISIONS = {"fp16": F16, "f16": F16, "half": F16, "fp32": F32, "f32": F32, "float": F32, "exact": F32}
+F16, F32, SPLIT = _lib.RS_PREC_F16, _lib.RS_PREC_F32, _lib.RS_PREC_SPLIT
+# "split": (hi, lo) fp16 pair storage, three fp16 MFMAs per product (fp32-class results at 1/3 of the fp16 matrix rate)
+PRECISIONS = {"fp16": F16, "f16": F16, "half": F16, "fp32": F32, "f32": F32, "float": F32, "exact": F32, "split": SPLIT,
+              "fp16x3": SPLIT}
 
 
 def parse_precision(p) -> int:
@@ -72,7 +74,7 @@ class Engine:
     """One native engine on the current device.  `unet_params` / `ae_params` are the YAML `params` blocks."""
 
     def __init__(self, unet_params: Optional[Mapping] = None, ae_params: Optional[Mapping] = None, enable_f16: bool = True,
-                 enable_f32: bool = True, device: Optional[torch.device] = None):
+                 enable_f32: bool = True, device: Optional[torch.device] = None, enable_split: bool = True):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("resshift_amd.Engine needs a HIP device; there is no CPU fallback")
@@ -84,7 +86,7 @@ class Engine:
         if ae_params is not None:
             _fill_ae(cfg.ae, ae_params)
             cfg.has_ae = 1
-        cfg.enable_f16, cfg.enable_f32 = int(enable_f16), int(enable_f32)
+        cfg.enable_f16, cfg.enable_f32, cfg.enable_split = int(enable_f16), int(enable_f32), int(enable_split)
         self.cfg = cfg
         self.unet_params, self.ae_params = unet_params, ae_params
         with torch.cuda.device(self.device):
@@ -272,9 +274,10 @@ class Engine:
 
     def profile_get(self) -> Dict[str, float]:
         """MFMA implicit-GEMM statistics of the last native call (see rs_profile_get)."""
-        out = (C.c_double * 5)()
+        out = (C.c_double * 9)()
         self.lib.rs_profile_get(self._h, out)
-        return {"flops_f16": out[0], "flops_f32": out[1], "igemm_ms": out[2], "igemm_launches": int(out[3]), "igemm_bytes": out[4]}
+        return {"flops_f16": out[0], "flops_f32": out[1], "igemm_ms": out[2], "igemm_launches": int(out[3]), "igemm_bytes": out[4],
+                "flops_split": out[5], "gn_ms": out[6], "gn_launches": int(out[7]), "gn_bytes": out[8]}
 
     def debug_enable(self, on: bool = True):
         self.lib.rs_debug_enable(self._h, int(on))

@@ -121,8 +121,13 @@ class ResShiftDiffusion:
         return ent[0]
 
     def adopt_engine(self, model: UNetModelSwin, ae: VQModelTorch, engine: Engine):
-        """Use an already-loaded engine (e.g. one whose weights arrived by RCCL broadcast) for this model pair."""
+        """Use an already-loaded engine (e.g. one whose weights arrived by RCCL broadcast) for this model pair.  The module
+        shells adopt it too: on ranks > 0 (and after a blob-cache hit) their own parameters were never filled, so
+        `model.engine()` / `autoencoder.engine()` - the step-wise API, `model(x, t)`, `encode` / `decode` - must not rebuild an
+        engine from those zeros."""
         self._fused[(id(model), id(ae))] = (engine, (params_version(model), params_version(ae)))
+        for m in (model, ae):
+            m._engine, m._engine_version = engine, params_version(m)
 
     # ---- reference API
     @staticmethod

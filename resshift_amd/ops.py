@@ -1,7 +1,8 @@
 """Thin torch-tensor wrappers over the op-level C-ABI entry points (rs_op_*).
 
 They exist so that tests/ can check every HIP kernel in isolation against a torch fp32 reference.
-Tensors are NHWC (channels last, contiguous) on the GPU; `prec` 0 = fp16 storage, 1 = fp32 storage.
+Tensors are NHWC (channels last, contiguous) on the GPU; `prec` 0 = fp16 storage, 1 = fp32 storage, 2 = split storage
+((hi, lo) fp16 pairs, 4 bytes per element: carried in torch.int32 tensors of the logical shape, see `convert`).
 """
 from __future__ import annotations
 
@@ -11,11 +12,25 @@ import torch
 
 from . import _lib
 
-F16, F32 = _lib.RS_PREC_F16, _lib.RS_PREC_F32
+F16, F32, SPLIT = _lib.RS_PREC_F16, _lib.RS_PREC_F32, _lib.RS_PREC_SPLIT
 
 
 def _dt(prec: int) -> torch.dtype:
-    return torch.float16 if prec == F16 else torch.float32
+    return {F16: torch.float16, F32: torch.float32, SPLIT: torch.int32}[prec]
+
+
+def _prec_of(t: torch.Tensor) -> int:
+    return {torch.float16: F16, torch.float32: F32, torch.int32: SPLIT}[t.dtype]
+
+
+def convert(x, prec):
+    """Storage conversion of an NHWC tensor [..., C] (fp16 / fp32 / split-as-int32) to `prec`."""
+    lib = _lib.load()
+    x = x.contiguous()
+    Cc = x.shape[-1]
+    out = torch.empty(x.shape, device=x.device, dtype=_dt(prec))
+    _lib.check(lib.rs_op_convert(x.data_ptr(), _prec_of(x), out.data_ptr(), prec, Cc, x.numel() // Cc, _lib.current_stream_ptr()), "convert")
+    return out
 
 
 def _hostf(t: torch.Tensor):
@@ -27,7 +42,7 @@ def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw
            force_direct=False):
     """x0: [B,H,W,C0] (+x1 [B,H,W,C1]); w_ref: reference layout [Cout,Cin,KH,KW]; returns [B,Ho,Wo,Cout]."""
     lib = _lib.load()
-    in_prec = F16 if x0.dtype == torch.float16 else F32
+    in_prec = _prec_of(x0)
     out_prec = in_prec if out_prec is None else out_prec
     B, Hs, Ws, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[-1]
@@ -52,7 +67,7 @@ def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw
 def gemm_nt(a, b, bias=None, scale=1.0, out_prec=None):
     """a: [nz,M,K], b: [nz,N,K] -> [nz,M,N] = scale * a @ b^T (+bias[n], fp32 device tensor)."""
     lib = _lib.load()
-    in_prec = F16 if a.dtype == torch.float16 else F32
+    in_prec = _prec_of(a)
     out_prec = in_prec if out_prec is None else out_prec
     nz, M, K = a.shape
     N = b.shape[1]
@@ -66,7 +81,7 @@ def gemm_nt(a, b, bias=None, scale=1.0, out_prec=None):
 def groupnorm(x, gamma, beta, eps, act=0, film=None, groups=32):
     """x: [B,H,W,C]; film: optional fp32 device tensor [2C] (scale, shift)."""
     lib = _lib.load()
-    prec = F16 if x.dtype == torch.float16 else F32
+    prec = _prec_of(x)
     B, H, W, Cc = x.shape
     y = torch.empty_like(x)
     gh, gp = _hostf(gamma)
@@ -80,7 +95,7 @@ def groupnorm(x, gamma, beta, eps, act=0, film=None, groups=32):
 def window_attention(qkv, table, heads, shift):
     """qkv: [B,H,W,3*heads*32]; table: [225,heads] relative_position_bias_table; returns [B,H,W,heads*32]."""
     lib = _lib.load()
-    prec = F16 if qkv.dtype == torch.float16 else F32
+    prec = _prec_of(qkv)
     B, H, W, _ = qkv.shape
     out = torch.empty(B, H, W, heads * 32, device=qkv.device, dtype=qkv.dtype)
     th, tp = _hostf(table)
@@ -151,7 +166,7 @@ def nchw_to_nhwc(x, prec=F32):
 def nhwc_to_nchw(x):
     lib = _lib.load()
     B, H, W, Cc = x.shape
-    prec = F16 if x.dtype == torch.float16 else F32
+    prec = _prec_of(x)
     out = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
     _lib.check(lib.rs_op_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), B, Cc, H * W, prec, _lib.current_stream_ptr()), "nhwc_to_nchw")
     return out

@@ -94,7 +94,7 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return F.pad(x, pad=(0, pad_w, 0, pad_h), mode="reflect")
 
 
-BLOB_CACHE_MAGIC = b"RSBLOB02"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+BLOB_CACHE_MAGIC = b"RSBLOB03"   # bump when the packed layout (csrc/engine.hip weight builder) changes
 
 
 def _blob_cache_load(path, eng) -> bool:
@@ -142,6 +142,7 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
             reload_model(model, unet_sd)
             reload_model(autoencoder, ae_sd)
         eng.load_state_dicts(unet_sd=model.state_dict(), ae_sd=autoencoder.state_dict())
+        eng._packed_from_modules = True
         if blob_cache:
             torch.cuda.synchronize(dev)
             _blob_cache_save(blob_cache, eng)
@@ -150,4 +151,12 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
         broadcast_blob(eng.weight_blob(), src=0)
         torch.cuda.synchronize(dev)
     eng.mark_weights_ready()
+    # the module shells hand out THIS engine from now on (model(x, t), encode / decode, the step-wise sampling API): on ranks
+    # other than 0, and on rank 0 after a blob-cache hit, their own parameters were never filled - an engine rebuilt from
+    # them would compute on zeros.  (`state_dict()` of such a shell is NOT the checkpoint; only the engine owns the weights.)
+    from .unet import params_version
+
+    for m in (model, autoencoder):
+        m._engine, m._engine_version = eng, params_version(m)
+    model.weights_in_engine_only = autoencoder.weights_in_engine_only = not (rank == 0 and getattr(eng, "_packed_from_modules", False))
     return eng

@@ -1,6 +1,6 @@
 """GPU micro-benchmark of the implicit-GEMM kernel on the real layer shapes of realsr_swinunet_realesrgan256 at B=32.
 
-    python scripts/igemm_bench.py [fp16|fp32] [reps]
+    python scripts/igemm_bench.py [fp16|fp32|split] [reps]
 
 Prints ms / TFLOP/s per shape and the weighted total for one full sampling pass (counts = launches per pass).
 """
@@ -15,8 +15,19 @@ from resshift_amd import _lib  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-P = 0 if prec == "fp16" else 1
+P = {"fp16": 0, "fp32": 1, "split": 2}[prec]
 dt = torch.float16 if P == 0 else torch.float32
+
+
+def to_store(t):
+    """fp32 device tensor [..., C] -> storage of the benchmarked precision (split: [..., C hi | C lo] fp16 pairs, common.h)"""
+    if P != 2:
+        return t.to(dt)
+    hi = t.half()
+    lo = ((t - hi.float()) * 2048.0).half()
+    return torch.cat([hi, lo], dim=-1).contiguous()
+
+
 B = 32
 # name, H(out), Cin, Cout, k, stride, up, act, res, launches per pass (15 UNet forwards + AE)
 U = 15
@@ -68,11 +79,11 @@ tot_ms = tot_fl = 0.0
 print(f"{'shape':28s} {'M':>8s} {'N':>5s} {'K':>6s} {'ms':>8s} {'TF/s':>8s} {'n/pass':>6s} {'ms/pass':>8s}")
 for name, Ho, Cin, Cout, k, stride, up, act, res, cnt in SHAPES:
     Hs = Ho * stride // up
-    x = torch.randn(B, Hs, Hs, Cin, device=dev).to(dt)
-    w = (torch.randn(Cout, k * k * Cin, device=dev) / (k * k * Cin) ** 0.5).to(dt)
+    x = to_store(torch.randn(B, Hs, Hs, Cin, device=dev))
+    w = to_store(torch.randn(Cout, k * k * Cin, device=dev) / (k * k * Cin) ** 0.5)
     bias = torch.randn(Cout, device=dev)
-    y = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=dt)
-    r = torch.randn(B, Ho, Ho, Cout, device=dev).to(dt) if res else None
+    y = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=torch.float32 if P == 2 else dt)   # (split: 4 bytes per element)
+    r = to_store(torch.randn(B, Ho, Ho, Cout, device=dev)) if res else None
     ms = C.c_float(0)
     rc = lib.rs_op_conv2d_bench(x.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, Hs, Hs,
                                 Cin, Cout, k, k, stride, k // 2, Ho, Ho, up, act, P, P, reps, C.byref(ms), st)

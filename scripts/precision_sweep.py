@@ -28,7 +28,14 @@ policies = {
     "last1+enc32": pol(1, enc="fp32"), "last2+enc32": pol(2, enc="fp32"), "last4+enc32": pol(4, enc="fp32"),
     "unet32": (["fp32"] * T, "fp16", "fp16"), "unet32+enc32": (["fp32"] * T, "fp32", "fp16"),
     "dec32": pol(0, dec="fp32"),
+    # split storage: (hi, lo) fp16 pairs, 3 fp16 MFMAs per product (fp32-class)
+    "split": (["split"] * T, "split", "split"),
+    "split+dec16": (["split"] * T, "split", "fp16"),
+    "unet-split": (["split"] * T, "fp16", "fp16"),
+    "split-last8+enc": (["split" if t < 8 else "fp16" for t in range(T)], "split", "fp16"),
 }
+if len(sys.argv) > 1:
+    policies = {k: policies[k] for k in sys.argv[1:]}
 yb = y.repeat(32, 1, 1, 1).to(dev); nb = torch.stack(noises, 0).repeat(1, 32, 1, 1, 1).to(dev)
 for name, (pu, pe, pd) in policies.items():
     d.set_precision(pu, pe, pd)

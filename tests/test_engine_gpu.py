@@ -17,7 +17,7 @@ from oracle import resshift_oracle as oc
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL_NET = {"fp32": 2e-4, "fp16": 3e-2}
+TOL_NET = {"fp32": 2e-4, "fp16": 3e-2, "split": 2e-4}   # split: (hi, lo) fp16 pairs + 3 MFMAs per product = fp32-class
 
 
 def _shells(up, ap, usd, asd, dev):
@@ -30,7 +30,7 @@ def _shells(up, ap, usd, asd, dev):
     return um.eval(), am.eval()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
 @pytest.mark.parametrize("tag", list(H.CASES))
 def test_unet_forward_vs_oracle(gpu, tag, prec):
     up, ap, dp, with_mask = H.CASES[tag]
@@ -51,7 +51,7 @@ def test_unet_forward_vs_oracle(gpu, tag, prec):
         assert H.rel_err(got, torch.from_numpy(H.golden()[f"{tag}/unet"])) < TOL_NET[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
 @pytest.mark.parametrize("tag", ["tiny", "tiny_fe8"])
 def test_autoencoder_vs_oracle(gpu, tag, prec):
     up, ap, dp, _ = H.CASES[tag]
@@ -78,7 +78,7 @@ def test_autoencoder_vs_oracle(gpu, tag, prec):
     assert H.rel_err(am.decode(zin.to(gpu), force_not_quantize=True, prec=prec), ref_nq) < TOL_NET[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
 @pytest.mark.parametrize("tag", list(H.CASES))
 def test_sample_loop_vs_oracle(gpu, tag, prec):
     """The fused native loop (rs_sample) and the step-wise API against the oracle loop with injected noise."""
@@ -101,7 +101,9 @@ def test_sample_loop_vs_oracle(gpu, tag, prec):
     agree = (gaux["indices"].cpu().long() == aux["indices"]).float().mean().item()
     p = H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1))
     print(f"sample {tag} {prec}: latent rel err {zerr:.3e}, VQ agreement {agree:.4f}, image PSNR {p:.1f} dB")
-    assert zerr < (5e-4 if prec == "fp32" else 6e-2)
+    assert zerr < (6e-2 if prec == "fp16" else 5e-4)
+    if prec == "split":
+        assert agree >= 0.99 and p >= 60.0
     if prec == "fp32":
         assert agree >= 0.99 and p >= 60.0
         assert H.psnr(out.cpu().clamp(-1, 1), torch.from_numpy(H.golden()[f"{tag}/sample"]).clamp(-1, 1)) >= 60.0

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header_sizes():
     L, S = _lib.RS_MAX_LEVELS, _lib.RS_MAX_STEPS
     assert ctypes.sizeof(_lib.UNetConfig) == 4 * (5 + L + L + 1 + L + 4 + 1 + 3)
     assert ctypes.sizeof(_lib.AEConfig) == 4 * (2 + L + L + 6 + 1 + L)
-    assert ctypes.sizeof(_lib.Config) == ctypes.sizeof(_lib.UNetConfig) + ctypes.sizeof(_lib.AEConfig) + 16
+    assert ctypes.sizeof(_lib.Config) == ctypes.sizeof(_lib.UNetConfig) + ctypes.sizeof(_lib.AEConfig) + 20
     assert ctypes.sizeof(_lib.SampleArgs) == 6 * 8 + 5 * 4 + 4 * S * 4 + S * 4 + 2 * 4 + 2 * 4 + S * 4 + 4 + 8
 
 

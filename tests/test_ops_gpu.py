@@ -395,3 +395,145 @@ def test_window_attention_fused_qkv(gpu, hw, shift):
     out2 = ops.window_attention_qkv(xd, wqkv, bqkv, table, heads, shift, wproj=wproj, bproj=bproj, res=rd)
     torch.cuda.synchronize()
     _close(out2.permute(0, 3, 1, 2), ref2, 3e-3, f"fused qkv + proj window attention {hw} shift {shift}")
+
+
+# ---------------------------------------------------------------- split storage (RS_PREC_SPLIT): (hi, lo) fp16 pairs, 3 MFMAs per product
+# Reference: float64 torch ops on the SAME fp32 inputs / weights.  The pair keeps 2^-23 of every operand and the kernel drops
+# only the lo*lo term (2^-24), so results are fp32-class: tolerance 2e-6 of the tensor's max (the exact fp32 MFMA path is
+# checked at 2e-5 against an fp32 reference above).
+TOL_SPLIT = 2e-6
+
+
+def _split(x_nchw, dev):
+    """fp32 NCHW (CPU) -> split-storage NHWC device tensor (int32 carrier)"""
+    from resshift_amd import ops
+
+    return ops.convert(x_nchw.permute(0, 2, 3, 1).contiguous().to(dev, torch.float32), ops.SPLIT)
+
+
+def _unsplit(t):
+    from resshift_amd import ops
+
+    return ops.convert(t, ops.F32).cpu()
+
+
+def test_split_storage_roundtrip(gpu):
+    """x -> (hi, lo) -> x: error <= 2^-22 |x| + 2^-35 (lo is kept scaled by 2^11, so it stays a NORMAL fp16 number down to
+    |x| ~ 2^-14; below that the absolute floor of the fp16 subnormals, 2^-24 / 2^11, takes over)"""
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 9, 11, 40, generator=g) * torch.logspace(-3, 2, 40)
+    xs = ops.convert(x.to(gpu), ops.SPLIT)
+    back = ops.convert(xs, ops.F32).cpu()
+    err, bound = (back - x).abs(), x.abs() * 2.0 ** -22 + 2.0 ** -35
+    bad = err > bound
+    assert not bad.any(), (int(bad.sum()), x[bad][:4].tolist(), back[bad][:4].tolist())
+    hi = xs.cpu().view(torch.float16).view(3, 9, 11, 2, 40)[..., 0, :]   # pixel record = [C hi | C lo]
+    assert torch.equal(hi, x.half())                     # the hi part alone is the fp16 rounding of x
+    assert torch.equal(ops.convert(x.half().to(gpu), ops.F32).cpu(), x.half().float())
+
+
+SPLIT_CONV_CASES = CONV_CASES + [
+    # B, H, W, Cin, Cout, k, stride, pad, up, act, res, asym  - larger launches: 128-pixel tiles, every channel tile, ragged M
+    (8, 64, 64, 160, 160, 3, 1, (1, 1), 1, 0, True, False),
+    (4, 64, 64, 192, 576, 1, 1, (0, 0), 1, 0, False, False),
+    (4, 64, 64, 192, 768, 1, 1, (0, 0), 1, 1, False, False),
+    (9, 60, 52, 160, 320, 3, 1, (1, 1), 1, 2, True, False),
+    (2, 64, 64, 160, 3, 3, 1, (1, 1), 1, 0, False, False),     # out head: Cout = 3 -> 64-channel tile
+    (2, 64, 64, 8, 160, 3, 1, (1, 1), 1, 0, False, False),     # input conv: 8 (zero padded) channels, K = 72
+    (32, 8, 8, 640, 640, 3, 1, (1, 1), 1, 0, True, False),     # 8x8 level at batch 32: 64-pixel tiles + split-K
+]
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("case", SPLIT_CONV_CASES)
+def test_conv_igemm_split(gpu, case, out_f32):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, k, stride, pad, up, act, use_res, asym = case
+    if out_f32 and (use_res or act):
+        pytest.skip("fp32 outputs are only produced by the heads (no residual / activation)")
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xr = x.double()
+    if up == 2:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if asym:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.double(), b.double(), stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xr, w.double(), b.double(), stride=stride, padding=pad[0])
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.silu(ref)
+    res_d = None
+    if use_res:
+        r = torch.randn(ref.shape, generator=g)
+        res_d = _split(r, gpu)
+        ref = ref + r.double()
+    y = ops.conv2d(_split(x, gpu), w, b, res=res_d, stride=stride, pad=pad, out_hw=(ref.shape[2], ref.shape[3]), up=up, act=act,
+                   out_prec=ops.F32 if out_f32 else None)
+    torch.cuda.synchronize()
+    yf = y.cpu() if out_f32 else _unsplit(y)
+    _close(yf.permute(0, 3, 1, 2), ref, TOL_SPLIT, f"split conv {case}")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 160), (1, 8, 8, 1280), (2, 32, 32, 192), (1, 64, 64, 128), (1, 16, 12, 480)])
+@pytest.mark.parametrize("mode", ["plain", "film_silu"])
+def test_groupnorm_split(gpu, shape, mode):
+    from resshift_amd import ops
+
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    eps = 1e-5 if mode != "plain" else 1e-6
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), eps)
+    film_d = None
+    if mode == "film_silu":
+        film = torch.randn(2 * C, generator=g) * 0.5
+        film_d = film.to(gpu)
+        ref = F.silu(ref * (1 + film[:C].double().view(1, C, 1, 1)) + film[C:].double().view(1, C, 1, 1))
+    y = ops.groupnorm(_split(x, gpu), gamma, beta, eps, act=0 if mode == "plain" else 2, film=film_d)
+    torch.cuda.synchronize()
+    _close(_unsplit(y).permute(0, 3, 1, 2), ref, 5e-6, f"split groupnorm {shape} {mode}")
+
+
+@pytest.mark.parametrize("hw,shift", [((16, 16), 0), ((32, 16), 4)])
+def test_window_attention_split(gpu, hw, shift):
+    from resshift_amd import ops
+
+    H, W = hw
+    heads = 6
+    g = torch.Generator().manual_seed(H * 7 + shift)
+    qkv = torch.randn(2, 3 * heads * 32, H, W, generator=g)
+    table = torch.randn(225, heads, generator=g) * 0.5
+    ref = _window_attention_reference(qkv.double(), table.double(), heads, shift)
+    out = ops.window_attention(_split(qkv, gpu), table, heads, shift)
+    torch.cuda.synchronize()
+    _close(_unsplit(out).permute(0, 3, 1, 2), ref, 5e-6, f"split window attention {hw} shift {shift}")
+
+
+def test_gemm_nt_batched_and_softmax_split(gpu):
+    """AE mid-block attention in split storage: S = q k^T (fp32 out), softmax -> split P, o = P v + b"""
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    nz, T, Cc = 2, 256, 512
+    q, k, v = (torch.randn(nz, T, Cc, generator=g) for _ in range(3))
+    qs, ks = ops.convert(q.to(gpu), ops.SPLIT), ops.convert(k.to(gpu), ops.SPLIT)
+    s = ops.gemm_nt(qs, ks, scale=Cc ** -0.5, out_prec=ops.F32)
+    torch.cuda.synchronize()
+    _close(s, (q.double() @ k.double().transpose(1, 2)) * Cc ** -0.5, TOL_SPLIT, "split QK^T")
+    p = ops.softmax_rows(s.view(nz * T, T), out_prec=ops.SPLIT)
+    torch.cuda.synchronize()
+    pr = s.double().cpu().view(nz * T, T).softmax(-1)
+    _close(_unsplit(p), pr, 5e-6, "softmax -> split")
+    vt = ops.convert(v.transpose(1, 2).contiguous().to(gpu), ops.SPLIT)
+    bias = torch.randn(Cc, generator=g).to(gpu)
+    o = ops.gemm_nt(p.view(nz, T, T), vt, bias=bias)
+    torch.cuda.synchronize()
+    _close(_unsplit(o), pr.view(nz, T, T) @ v.double() + bias.cpu().double(), 5e-6, "split PV")
