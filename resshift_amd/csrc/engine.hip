@@ -1227,6 +1227,13 @@ int rs_unet_forward(rs_engine* e, const float* x, const int* t_host, const float
     }
     hipStream_t st = (hipStream_t)stream;
     if (!e->ready) return fail("weights are not ready");
+    if (B < 1 || !x || !out || !t_host) return fail("rs_unet_forward: bad batch / null tensor");
+    if (e->cfg.unet.cond_lq && !lq) return fail("rs_unet_forward: this UNet is conditioned on lq (cond_lq) but lq is NULL");
+    if (e->cfg.unet.cond_mask && !mask) return fail("rs_unet_forward: this UNet is conditioned on a mask (cond_mask) but mask is NULL");
+    if (e->cfg.unet.cond_lq && e->fe_convs.empty() && (Hl != H || Wl != W))
+        return fail("rs_unet_forward: without a feature extractor lq must have the latent resolution");
+    if (!e->fe_convs.empty() && ((Hl >> (int)e->fe_convs.size()) != H || (Wl >> (int)e->fe_convs.size()) != W))
+        return fail("rs_unet_forward: lq resolution does not match the feature extractor's down-sampling");
     for (int b = 1; b < B; ++b) if (t_host[b] != t_host[0]) return fail("rs_unet_forward: per-sample timesteps must be equal within a batch");
     const float* film = e->film_row(t_host[0], st);
     if (!film) return fail("FiLM table allocation failed");
@@ -1290,6 +1297,15 @@ int rs_sample(rs_engine* e, const rs_sample_args* a) {
     const int f = 1 << (ae.n_levels - 1);
     const int B = a->B, Hi = a->h * a->sf, Wi = a->w * a->sf, hz = Hi / f, wz = Wi / f, Cz = ae.embed_dim;
     if (e->cfg.unet.in_channels != Cz) return fail("UNet in_channels != AE embed_dim");
+    if (B < 1 || a->h < 1 || a->w < 1 || a->sf < 1 || !a->y || !a->noise || !a->out) return fail("rs_sample: bad batch / size / null tensor");
+    if ((Hi % f) || (Wi % f)) return fail("rs_sample: h*sf and w*sf must be multiples of the autoencoder's down-sampling factor");
+    {
+        const int sh = e->cfg.unet.n_levels - 1;
+        if ((hz % (8 << sh)) || (wz % (8 << sh))) return fail("rs_sample: latent H/W must be multiples of 8*2^(levels-1) (pad the input, sampler.py:130-138)");
+    }
+    if (e->cfg.unet.cond_lq && e->fe_convs.empty() && (a->h != hz || a->w != wz))
+        return fail("rs_sample: without a feature extractor the LQ image is concatenated at latent resolution: h*sf/f must equal h");
+    if (e->cfg.unet.cond_mask && !a->mask) return fail("rs_sample: this UNet is conditioned on a mask (cond_mask) but mask is NULL");
     std::vector<const float*> films(a->steps);
     for (int t = 0; t < a->steps; ++t) {
         films[t] = e->film_row(a->tmap[t], st);

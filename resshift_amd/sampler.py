@@ -114,7 +114,8 @@ class BaseSampler:
         eng = sharding.build_engine_with_broadcast(
             model, autoencoder,
             load_fn=lambda: (self._load_sd("model", c["model"].get("ckpt_path")), self._load_sd("autoencoder", c["autoencoder"].get("ckpt_path"))),
-            rank=self.rank, world=self.num_gpus, blob_cache=self._blob_cache)
+            rank=self.rank, world=self.num_gpus, blob_cache=self._blob_cache,
+            cache_fingerprint=sharding.checkpoint_fingerprint([c["model"].get("ckpt_path"), c["autoencoder"].get("ckpt_path")]))
         self.base_diffusion.adopt_engine(model, autoencoder, eng)
         self.model = model.eval()
         self.autoencoder = autoencoder.eval()
@@ -141,6 +142,8 @@ class ResShiftSampler(BaseSampler):
             pad_w = (math.ceil(ori_w / offset)) * offset - ori_w
             y0 = sharding.reflect_pad(y0, pad_h, pad_w)
             if mask is not None:
+                # (deviation: the reference pads y0 only, sampler.py:130-138, and then fails in the UNet's channel concat when an
+                # inpainting input needs padding; padding the mask alike keeps such inputs usable and changes nothing otherwise)
                 mask = sharding.reflect_pad(mask, pad_h, pad_w)
         cond_lq = self.configs["model"]["params"].get("cond_lq", True)
         if cond_lq and mask is not None:
@@ -197,19 +200,28 @@ class ResShiftSampler(BaseSampler):
         if self.rank == 0:
             out_path.mkdir(parents=True, exist_ok=True)
         sharding.barrier()
-        files = sorted([p for p in (in_path.glob("*") if in_path.is_dir() else [in_path])
-                        if p.suffix.lower() in (".png", ".jpg", ".jpeg", ".bmp")])
+        single = not in_path.is_dir()
+        if single:
+            files = [in_path]
+        else:
+            # utils/util_common.py:68-87 with recursive=True (sampler.py:246,258): one recursive glob per extension, in the
+            # reference's extension order, each sorted; the inpainting loader adds 'PNG' (sampler.py:259)
+            exts = ["png", "jpg", "jpeg", "JPEG", "bmp"] + (["PNG"] if mask_path is not None else [])
+            files = [p for e in exts for p in sorted(in_path.glob(f"**/*.{e}"))]
         from PIL import Image
 
+        micro = math.ceil(bs / self.num_gpus)   # sampler.py:274-277: the slice width comes from bs, also on the last, partial batch
         for b0 in range(0, len(files), bs):
             batch = files[b0:b0 + bs]
-            lo, hi = sharding.shard_bounds(len(batch), self.rank, self.num_gpus)
-            mine = batch[lo:hi]
+            mine = batch[self.rank * micro:(self.rank + 1) * micro]
             if mine:
                 lq = self.engine.u8_to_input(torch.stack([self._read_image_u8(p) for p in mine]).to(self.device))
                 mask = None
                 if mask_path is not None:
-                    mask = self.engine.u8_to_input(torch.stack([self._read_image_u8(Path(mask_path) / p.name, gray=True) for p in mine]).to(self.device))
+                    # a directory input looks the mask up by file name (datapipe/datasets.py:470); a single input file takes
+                    # mask_path as the mask file itself (sampler.py:296-297)
+                    mpaths = [Path(mask_path)] if single else [Path(mask_path) / p.name for p in mine]
+                    mask = self.engine.u8_to_input(torch.stack([self._read_image_u8(m, gray=True) for m in mpaths]).to(self.device))
                 sr = self.sample_tiled(lq, mask=mask, noise_repeat=noise_repeat)
                 blend = mask is not None and mask_back
                 out_u8 = self.engine.output_to_u8(sr, lq=lq if blend else None, mask=mask if blend else None).cpu().numpy()

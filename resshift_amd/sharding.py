@@ -97,14 +97,35 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
 BLOB_CACHE_MAGIC = b"RSBLOB03"   # bump when the packed layout (csrc/engine.hip weight builder) changes
 
 
-def _blob_cache_load(path, eng) -> bool:
-    """Fill the engine's device blob from a packed-blob cache file; False when absent / stale (size or magic)."""
+def checkpoint_fingerprint(paths) -> bytes:
+    """16 bytes identifying the checkpoint files a blob was packed from (path, size, mtime): two checkpoints of one
+    architecture (realsr v1 / v2, a retrained ckpt_path) give the same blob size, so the size alone cannot tell a stale cache."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in paths or ():
+        if p is None:
+            h.update(b"<none>")
+            continue
+        p = os.path.abspath(str(p))
+        h.update(p.encode())
+        try:
+            st = os.stat(p)
+            h.update(f"{st.st_size}:{st.st_mtime_ns}".encode())
+        except OSError:
+            h.update(b"<missing>")
+    return h.digest()[:16]
+
+
+def _blob_cache_load(path, eng, fingerprint: bytes = b"\0" * 16) -> bool:
+    """Fill the engine's device blob from a packed-blob cache file; False when absent / stale (magic, size or the fingerprint
+    of the checkpoints it was packed from)."""
     if not path or not os.path.exists(path):
         return False
     blob = eng.weight_blob()
     with open(path, "rb") as fh:
-        head = fh.read(16)
-        if head[:8] != BLOB_CACHE_MAGIC or int.from_bytes(head[8:16], "little") != blob.numel():
+        head = fh.read(32)
+        if len(head) != 32 or head[:8] != BLOB_CACHE_MAGIC or int.from_bytes(head[8:16], "little") != blob.numel() or head[16:32] != fingerprint:
             return False
         import numpy as np
 
@@ -115,20 +136,22 @@ def _blob_cache_load(path, eng) -> bool:
     return True
 
 
-def _blob_cache_save(path, eng) -> None:
+def _blob_cache_save(path, eng, fingerprint: bytes = b"\0" * 16) -> None:
     blob = eng.weight_blob().cpu().numpy()
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "wb") as fh:
-        fh.write(BLOB_CACHE_MAGIC + int(blob.size).to_bytes(8, "little"))
+        fh.write(BLOB_CACHE_MAGIC + int(blob.size).to_bytes(8, "little") + fingerprint)
         blob.tofile(fh)
     os.replace(tmp, path)
 
 
-def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int, blob_cache=None):
+def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int, blob_cache=None,
+                                cache_fingerprint: bytes = b"\0" * 16):
     """Create the fused UNet+AE engine on this rank's GPU.  Rank 0 calls `load_fn()` -> (unet_sd, ae_sd), fills the
     drop-in modules (reload_model semantics) and packs the device blob; the blob is then broadcast.
 
-    `blob_cache`: path of a packed-blob file.  When it exists (and matches this configuration's blob size) rank 0 uploads
+    `blob_cache`: path of a packed-blob file.  When it exists (and matches this configuration's blob size and
+    `cache_fingerprint`, see checkpoint_fingerprint) rank 0 uploads
     it instead of reading and repacking the checkpoints - the drop-in modules then keep their initial parameters, only
     the engine owns the real weights; otherwise the freshly packed blob is written there for the next start."""
     from .engine import Engine
@@ -136,7 +159,7 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
 
     dev = next(model.parameters()).device
     eng = Engine(unet_params=model.params, ae_params=autoencoder.params, device=dev)
-    if rank == 0 and not _blob_cache_load(blob_cache, eng):
+    if rank == 0 and not _blob_cache_load(blob_cache, eng, cache_fingerprint):
         unet_sd, ae_sd = load_fn()
         with torch.no_grad():
             reload_model(model, unet_sd)
@@ -145,7 +168,7 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
         eng._packed_from_modules = True
         if blob_cache:
             torch.cuda.synchronize(dev)
-            _blob_cache_save(blob_cache, eng)
+            _blob_cache_save(blob_cache, eng, cache_fingerprint)
     if world > 1:
         torch.cuda.synchronize(dev)
         broadcast_blob(eng.weight_blob(), src=0)

@@ -56,8 +56,11 @@ class TileSplitter:
         cur = self.starts[self.count_pchs:self.count_pchs + self.extra_bs]
         self.count_pchs += len(cur)
         ps, sf = self.pch_size, self.sf
+        H, W = self.im_ori.shape[2:]
         pch = torch.cat([self.im_ori[:, :, h0:h0 + ps, w0:w0 + ps] for h0, w0 in cur], dim=0)
-        index_infos = [[h0 * sf, (h0 + ps) * sf, w0 * sf, (w0 + ps) * sf] for h0, w0 in cur]
+        # a side that is <= pch_size yields a shorter tile (the slice clamps, as the reference's does, util_image.py:946-952):
+        # the canvas window is clamped likewise (the reference's slice ASSIGNMENT clamps it, :962-968)
+        index_infos = [[h0 * sf, min(h0 + ps, H) * sf, w0 * sf, min(w0 + ps, W) * sf] for h0, w0 in cur]
         return pch, index_infos
 
     def update(self, pch_res: torch.Tensor, index_infos) -> None:
@@ -70,7 +73,10 @@ class TileSplitter:
             self.pixel_count = torch.zeros(H * self.sf, W * self.sf, device=pch_res.device, dtype=torch.float32)
         B, Cc, H, W = self.im_res.shape
         st = _lib.current_stream_ptr()
+        th, tw = pch_res.shape[2:]
         for k, (h0, h1, w0, w1) in enumerate(index_infos):
+            if (h1 - h0, w1 - w0) != (th, tw):   # the kernel reads the tile with row pitch tw
+                raise ValueError(f"tile result is {th}x{tw} but its canvas window is {h1 - h0}x{w1 - w0}")
             tile = pch_res[k * self.true_bs:(k + 1) * self.true_bs]
             rc = self.lib.rs_tile_accumulate(self.im_res.data_ptr(), self.pixel_count.data_ptr(), tile.data_ptr(), B, Cc, H, W, h0, w0,
                                              h1 - h0, w1 - w0, st)

@@ -2,10 +2,12 @@
 oracle on identical seeded weights, inputs and injected noise, and against the committed reference outputs.
 
 Tolerances (floating point path, per north_star):
-  * fp32 mode (exact fp32 MFMA): relative max error <= 2e-4 per network call; image PSNR >= 60 dB;
-  * fp16 mode (fp16 storage / fp32 accumulate): relative max error <= 3e-2 per network call; latent PSNR and
+  * fp32 mode (exact fp32 MFMA) and split mode ((hi, lo) fp16 pairs, 3 MFMAs per product): relative max error <= 2e-5
+    per network call; image PSNR >= 60 dB and VQ code agreement >= 0.999 through the whole loop, also at batch 32;
+  * fp16 mode (fp16 storage / fp32 accumulate): relative max error <= 5e-3 per network call; latent PSNR and
     VQ index agreement are reported, image PSNR with the reference's indices forced must be >= 60 dB
-    (the VQ argmin discontinuity is the only thing separating the two — SURVEY.md fact 5).
+    (test_decoder_with_the_reference_indices_forced: the VQ argmin discontinuity is the only thing separating
+    the two - SURVEY.md fact 5).
 """
 import numpy as np
 import pytest
@@ -17,7 +19,8 @@ from oracle import resshift_oracle as oc
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL_NET = {"fp32": 2e-4, "fp16": 3e-2, "split": 2e-4}   # split: (hi, lo) fp16 pairs + 3 MFMAs per product = fp32-class
+# measured on MI355X (round 2): fp32 1.1e-6 .. 2.4e-6, split 0.8e-6 .. 1.9e-6, fp16 1.1e-3 .. 2.7e-3 per network call
+TOL_NET = {"fp32": 2e-5, "fp16": 5e-3, "split": 2e-5}   # split: (hi, lo) fp16 pairs + 3 MFMAs per product = fp32-class
 
 
 def _shells(up, ap, usd, asd, dev):
@@ -101,7 +104,7 @@ def test_sample_loop_vs_oracle(gpu, tag, prec):
     agree = (gaux["indices"].cpu().long() == aux["indices"]).float().mean().item()
     p = H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1))
     print(f"sample {tag} {prec}: latent rel err {zerr:.3e}, VQ agreement {agree:.4f}, image PSNR {p:.1f} dB")
-    assert zerr < (6e-2 if prec == "fp16" else 5e-4)
+    assert zerr < (2e-2 if prec == "fp16" else 5e-5)   # measured: fp16 4.5e-3 .. 9.1e-3, fp32 / split 2e-6 .. 6e-6
     if prec == "split":
         assert agree >= 0.99 and p >= 60.0
     if prec == "fp32":
@@ -139,9 +142,9 @@ def test_realsr_full_size_vs_reference_output(gpu):
         print(f"realsr full {prec}: image PSNR {results[prec][0]:.1f} dB, latent PSNR {results[prec][1]:.1f} dB, VQ agreement {agree:.4f}")
     # UNet single forward against the reference's own output
     got = um(noises[1].to(gpu) * 1.3, [7], lq=y.to(gpu), prec="fp32")
-    assert H.rel_err(got, torch.from_numpy(g["realsr/unet"])) < 2e-4
+    assert H.rel_err(got, torch.from_numpy(g["realsr/unet"])) < 2e-5
     assert results["fp32"][0] >= 60.0 and results["fp32"][2] >= 0.995
-    assert results["fp16"][1] >= 40.0  # fp16 latent stays within fp16 tolerance of the fp32 trajectory
+    assert results["fp16"][1] >= 65.0  # fp16 latent stays within fp16 tolerance of the fp32 trajectory (measured 70 - 72 dB)
 
 
 def test_sampler_drop_in_sample_func(gpu):
@@ -199,7 +202,7 @@ def test_other_baseline_configs_full_size_vs_oracle(gpu, cname, hw, with_mask):
     zr = aux["z_final"]
     lat = H.psnr(g16["z_final"].cpu(), zr, peak_to_peak=(zr.max() - zr.min()).item())
     print(f"{cname} fp16: latent PSNR {lat:.1f} dB, image PSNR {H.psnr(out16.cpu().clamp(-1, 1), ref.clamp(-1, 1)):.1f} dB")
-    assert lat >= 40.0
+    assert lat >= 60.0   # measured 68.4 - 69.3 dB
 
 
 def test_tiled_large_image_path(gpu):
@@ -293,11 +296,24 @@ def test_checkpoint_ingestion_and_blob_cache(gpu, tmp_path):
     got = run(ResShiftSampler(_tiny_cfg(up, ap, dp, str(tmp_path / "unet.pth"), str(tmp_path / "ae.pth")), blob_cache=str(cache), **kw))
     assert torch.equal(got, ref)
     assert cache.exists() and cache.stat().st_size > 1000
-    again = run(ResShiftSampler(_tiny_cfg(up, ap, dp, "/nonexistent/unet.pth", "/nonexistent/ae.pth"), blob_cache=str(cache), **kw))
-    assert torch.equal(again, ref)
-    cache.write_bytes(cache.read_bytes()[:-7])  # truncated cache -> ignored, falls back to the checkpoints
-    with pytest.raises((FileNotFoundError, OSError)):
-        ResShiftSampler(_tiny_cfg(up, ap, dp, "/nonexistent/unet.pth", "/nonexistent/ae.pth"), blob_cache=str(cache), **kw)
+    cfg_same = _tiny_cfg(up, ap, dp, str(tmp_path / "unet.pth"), str(tmp_path / "ae.pth"))
+    real_load = torch.load
+
+    def no_load(*a, **k):
+        raise AssertionError("the checkpoints were opened although a valid blob cache exists")
+
+    torch.load = no_load
+    try:
+        again = run(ResShiftSampler(cfg_same, blob_cache=str(cache), **kw))
+        assert torch.equal(again, ref)
+        # another checkpoint of the same architecture (same blob size) under another path: the cache must NOT be used
+        with pytest.raises((AssertionError, FileNotFoundError, OSError)):
+            ResShiftSampler(_tiny_cfg(up, ap, dp, "/nonexistent/unet.pth", "/nonexistent/ae.pth"), blob_cache=str(cache), **kw)
+        cache.write_bytes(cache.read_bytes()[:-7])  # truncated cache -> ignored, falls back to the checkpoints
+        with pytest.raises(AssertionError):
+            ResShiftSampler(cfg_same, blob_cache=str(cache), **kw)
+    finally:
+        torch.load = real_load
 
 
 def test_inference_files_on_device_uint8(gpu, tmp_path):
@@ -348,3 +364,172 @@ def test_fused_swin_paths_match_unfused(gpu, tmp_path):
     err = H.rel_err(fused, plain)
     print(f"fused vs unfused Swin path: rel err {err:.2e}")
     assert err < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: parity at the headline batch size, the precision policies the bench reports, real pixels, forced VQ indices,
+# timestep respacing.
+
+
+def _realsr_models(gpu):
+    up, ap, dp = H.realsr_params()
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    return up, ap, dp, usd, asd, um, am
+
+
+def _real_lq(n):
+    """the reference's own validation inputs (testdata/Val_SR/lq, bundled by oracle/make_real_inputs.py) in [-1, 1]"""
+    import os
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "val_sr_lq.npz"))
+    x = torch.from_numpy(d["lq"][:n].astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    return (x / 255.0 - 0.5) / 0.5   # datapipe/datasets.py:59-63
+
+
+@pytest.mark.parametrize("inputs", ["synthetic", "real_pixels"])
+def test_batch32_parity_of_the_bench_policies(gpu, inputs):
+    """rs_sample at the headline batch size (B = 32: the in-graph kernel selection of the bench - igemm3, split-K plans, 64-pixel
+    tiles - differs from the B <= 2 tests above) against the CPU oracle on images 0, 13, 22 and 31 of the batch.
+      * `parity` policy (split-precision encoder + UNet, fp16 decoder): image PSNR >= 60 dB, VQ code agreement >= 0.999 -
+        north_star's acceptance bar, at the batch the throughput is quoted on;
+      * fp16 policy: latent PSNR >= 65 dB on the synthetic inputs (measured 70 - 75 dB), >= 50 dB on the natural images (measured
+        54.9 dB: smooth inputs make the random-init network's trajectory more sensitive); its image PSNR is bounded by the VQ
+        flips (reported, not asserted)."""
+    from resshift_amd import create_gaussian_diffusion
+
+    up, ap, dp, usd, asd, um, am = _realsr_models(gpu)
+    B, T = 32, dp["steps"]
+    y, noises, _ = H.synth.synthetic_inputs(77, B, 64, 64, 3, 64, 64, T)
+    if inputs == "real_pixels":
+        y = _real_lq(B)
+    pick = [0, 13, 22, 31]
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y[pick], [n[pick] for n in noises], return_aux=True)
+    zr = aux["z_final"]
+    d = create_gaussian_diffusion(**dp)
+    for name, pol, min_img, min_lat, min_agree in (("parity", (["split"] * T, "split", "fp16"), 60.0, 100.0, 0.999),
+                                                   ("fp16", (["fp16"] * T, "fp16", "fp16"), 0.0, 65.0 if inputs == "synthetic" else 50.0, 0.9)):
+        d.set_precision(*pol)
+        out, g = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False,
+                                 model_kwargs={"lq": y.to(gpu)}, step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+        torch.cuda.synchronize()
+        idx = g["indices"].cpu().long().view(B, -1)[pick].reshape(-1)
+        agree = (idx == aux["indices"].reshape(-1)).float().mean().item()
+        p_img = H.psnr(out.cpu()[pick].clamp(-1, 1), ref.clamp(-1, 1))
+        p_lat = H.psnr(g["z_final"].cpu()[pick], zr, peak_to_peak=(zr.max() - zr.min()).item())
+        print(f"B=32 {inputs} {name}: image PSNR {p_img:.1f} dB, latent PSNR {p_lat:.1f} dB, VQ agreement {agree:.5f}")
+        assert p_img >= min_img and p_lat >= min_lat and agree >= min_agree, (name, p_img, p_lat, agree)
+
+
+def test_decoder_with_the_reference_indices_forced(gpu):
+    """What separates the fp16 policy from the reference is ONLY the VQ argmin (ldm/modules/vqvae/quantize.py:276-285): with the
+    oracle's code indices forced (codebook rows fed through decode(force_not_quantize=True)) the fp16 decoder reproduces the
+    reference image to >= 60 dB, and so does the split / fp32 decoder."""
+    up, ap, dp, usd, asd, um, am = _realsr_models(gpu)
+    _, noises, _ = H.synth.synthetic_inputs(H.SEED_X, 2, 64, 64, 3, 64, 64, dp["steps"])
+    zin = noises[3] * 0.7
+    ref_img, ref_idx = oc.vq_decode(asd, ap, zin, return_indices=True)
+    zq = asd["quantize.embedding.weight"][ref_idx.reshape(-1)].view(2, 64, 64, 3).permute(0, 3, 1, 2).contiguous()
+    for prec, floor in (("fp16", 60.0), ("split", 100.0), ("fp32", 100.0)):
+        img = am.decode(zq.to(gpu), force_not_quantize=True, prec=prec)
+        torch.cuda.synchronize()
+        p = H.psnr(img.cpu().clamp(-1, 1), ref_img.clamp(-1, 1))
+        print(f"decoder with forced indices, {prec}: {p:.1f} dB")
+        assert p >= floor, (prec, p)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "split"])
+def test_timestep_respacing_non_identity_map(gpu, prec):
+    """respace.py:23-70 with timestep_respacing < steps: the loop runs on the kept steps, the UNet sees the ORIGINAL indices
+    (timestep_map != identity) - the tmap[] path of rs_sample."""
+    from resshift_amd import create_gaussian_diffusion
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    dp = dict(dp, steps=12, timestep_respacing=4)
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    d = create_gaussian_diffusion(**dp)
+    assert d.num_timesteps == 4 and d.timestep_map == [0, 3, 6, 9]
+    y, noises, _ = H.synth.synthetic_inputs(9, 2, 16, 16, 3, 16, 16, d.num_timesteps)
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, return_aux=True)
+    d.set_precision(prec, prec, prec)
+    out, g = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False,
+                             model_kwargs={"lq": y.to(gpu)}, step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    assert H.rel_err(g["z_final"], aux["z_final"]) < 5e-4
+    assert H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1)) >= 60.0
+
+
+@pytest.mark.parametrize("policy", ["fp32", "parity"])
+def test_two_ranks_share_one_gpu(gpu, tmp_path, policy):
+    """The full multi-rank path - build_engine_with_broadcast(world = 2) -> blob broadcast -> mark_weights_ready -> rank-sharded
+    batch with shard_noise -> fused loop -> gather - with two processes on the one GPU of the box (gloo rendezvous): the
+    gathered result must be BIT-IDENTICAL to the single-process run of the whole batch (images are independent units;
+    sampler.py:66-77,273-277)."""
+    import os
+    import subprocess
+    import sys
+
+    from resshift_amd import create_gaussian_diffusion
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = tmp_path / "two_rank.pt"
+    env = dict(os.environ, RESSHIFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(here, "_two_rank_worker.py"), str(out), policy]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    T = dp["steps"]
+    d = create_gaussian_diffusion(**dp)
+    d.set_precision(*{"fp32": ("fp32", "fp32", "fp32"), "parity": (["split"] * T, "split", "fp16")}[policy])
+    y, noises, _ = H.synth.synthetic_inputs(31, 5, 16, 16, 3, 16, 16, T)
+    ref = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False,
+                          model_kwargs={"lq": y.to(gpu)}, step_noises=[n.to(gpu) for n in noises[1:]])
+    torch.cuda.synchronize()
+    assert tuple(got["out"].shape) == tuple(ref.shape)
+    assert torch.equal(got["out"], ref.cpu()), (got["out"] - ref.cpu()).abs().max().item()
+    z = am.encode(torch.nn.functional.interpolate(y.to(gpu), scale_factor=4, mode="nearest"), prec="fp32")
+    assert abs(got["zsum"] - float(z.abs().sum())) <= 1e-3 * float(z.abs().sum()) and got["zsum"] > 0   # rank 1's shells used real weights
+
+
+def test_tiled_path_one_side_shorter_than_the_tile(gpu):
+    """an input with one side <= chop_size and the other larger (e.g. 480x640 with chop 512; here 12x40 with 16-pixel
+    tiles): the slice clamps the tile AND its canvas window, exactly like the reference's slice assignment
+    (utils/util_image.py:946-968)."""
+    from resshift_amd import ResShiftSampler
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    s = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, chop_size=16, chop_stride=12, chop_bs=1, padding_offset=16, seed=1,
+                        state_dicts={"model": usd, "autoencoder": asd})
+    g = torch.Generator().manual_seed(4)
+    y = torch.rand(1, 3, 12, 40, generator=g) * 2 - 1
+    n_tiles = 3   # columns 0, 12, 24 (36 is pulled back onto 24)
+    calls = [[torch.randn(1, 3, 16, 16, generator=g) for _ in range(dp["steps"] + 1)] for _ in range(n_tiles)]
+    ref = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=16, chop_stride=12, chop_bs=1, padding_offset=16)
+    out = s.sample_tiled(y.to(gpu), tile_noises=[(c[0].to(gpu), [n.to(gpu) for n in c[1:]]) for c in calls])
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1, 3, 48, 160) == tuple(ref.shape)
+    assert H.psnr(out.cpu(), ref) >= 60.0
+
+
+def test_engine_rejects_inconsistent_sample_arguments(gpu):
+    """rs_sample / rs_unet_forward validate their dimensions and the mask up front instead of faulting on the GPU"""
+    up, ap, dp, with_mask = H.CASES["tiny_fe"]
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    y, noises, mask = H.case_inputs(up, ap, dp, with_mask)
+    assert with_mask
+    with pytest.raises(RuntimeError, match="mask"):
+        um(noises[1].to(gpu), [1, 1], lq=y.to(gpu))              # cond_mask model without a mask
+    up0, ap0, dp0, _ = H.CASES["tiny"]
+    u0, a0 = H.weights(up0, ap0)
+    um0, am0 = _shells(up0, ap0, u0, a0, gpu)
+    with pytest.raises(RuntimeError, match="multiples"):
+        um0(torch.zeros(1, 3, 12, 16, device=gpu), [0], lq=torch.zeros(1, 3, 12, 16, device=gpu))
+    with pytest.raises(RuntimeError, match="latent resolution"):
+        um0(torch.zeros(1, 3, 16, 16, device=gpu), [0], lq=torch.zeros(1, 3, 32, 32, device=gpu))

@@ -242,6 +242,17 @@ def test_blob_cache_file_format_roundtrip_and_rejection(tmp_path):
     assert not sharding._blob_cache_load(path, dst)
     open(path, "wb").write(raw[:-5])                                        # truncated
     assert not sharding._blob_cache_load(path, dst)
+    # fingerprint of the checkpoints the blob was packed from (path, size, mtime): a retrained checkpoint of the same size
+    # or another path invalidates the cache
+    ck = tmp_path / "a.pth"
+    ck.write_bytes(b"x" * 10)
+    fp = sharding.checkpoint_fingerprint([str(ck), None])
+    sharding._blob_cache_save(path, src, fp)
+    assert sharding._blob_cache_load(path, dst, fp)
+    assert not sharding._blob_cache_load(path, dst)                                                    # no fingerprint given
+    assert not sharding._blob_cache_load(path, dst, sharding.checkpoint_fingerprint([str(tmp_path / "b.pth"), None]))
+    ck.write_bytes(b"y" * 11)
+    assert not sharding._blob_cache_load(path, dst, sharding.checkpoint_fingerprint([str(ck), None]))
 
 
 def _kernel_resource_table(lib_path):

@@ -154,3 +154,21 @@ def test_tiled_path_oracle_vs_reference_golden():
     got = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=mt.CHOP_SIZE, chop_stride=mt.CHOP_STRIDE, chop_bs=mt.CHOP_BS,
                           padding_offset=mt.PAD_OFFSET)
     assert (got - torch.from_numpy(g["sample"])).abs().max().item() <= 2e-5
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_respaced_schedule_live_against_reference():
+    """timestep_respacing < steps (respace.py:23-70): the oracle's and the product's tables and timestep map against the
+    reference's own SpacedDiffusion object."""
+    from resshift_amd import create_gaussian_diffusion
+
+    _, _, create = ref_import.load()
+    dp = dict(H.CASES["tiny"][2], steps=12, timestep_respacing=4)
+    ref = create(**dp)
+    s = oc.Schedule(dp)
+    mine = create_gaussian_diffusion(**dp)
+    assert list(ref.timestep_map) == s.timestep_map == mine.timestep_map == [0, 3, 6, 9]
+    for name in ("sqrt_etas", "etas", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped"):
+        r = np.asarray(getattr(ref, name), dtype=np.float64)
+        assert np.array_equal(r, np.asarray(getattr(s, name), dtype=np.float64)), name
+        assert np.array_equal(r, np.asarray(getattr(mine, name), dtype=np.float64)), name
