@@ -765,22 +765,36 @@ struct rs_engine {
         conv1(ex, a.q, n, q);
         conv1(ex, a.k, n, k);
         View o = ex.T(X.B, X.H, X.W, C, dt);
+        // The score matrix is materialised, but never more than `budget` floats of it at a time (4 GiB of fp32 S + the same
+        // number of P elements): several images per pass while a whole T x T matrix fits (the 64 x 64 latents of the shipped
+        // configs: T = 4096), otherwise one image in blocks of query rows (softmax is row-wise, so row blocks are independent).
+        // That is what lets the tiled path run the reference's real tile sizes (inference_resshift.py:149-161): a 256 x 256 LR
+        // tile is T = 65 536 tokens, 512 x 512 T = 262 144.  At d = 512 a flash-style kernel would have to stream a 64 KB K
+        // tile AND a 64 KB V tile through LDS per 64 keys (one ds_read_b128 per MFMA: LDS-bound); the two GEMMs + row softmax
+        // run on the tuned implicit-GEMM path instead and their scratch is bounded here.
+        static const size_t budget = []() { const char* e = getenv("RS_ATTN_S_FLOATS"); return e ? (size_t)atoll(e) : ((size_t)1 << 30); }();
         const size_t tt = (size_t)T * T;
-        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)X.B, ((size_t)1 << 30) / tt));  // <= 4 GiB of fp32 S
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)X.B, budget / tt));
+        int rows = T;
+        if (tt > budget) rows = (int)std::max<size_t>(128, std::min<size_t>((size_t)T, (budget / (size_t)T) / 128 * 128));
         const size_t es = rs_dtype_size(dt);
         char* vT = (char*)ex.raw((size_t)chunk * C * T * es);
-        float* S = (float*)ex.raw((size_t)chunk * T * T * sizeof(float));
-        char* P = (char*)ex.raw((size_t)chunk * T * T * es);
+        float* S = (float*)ex.raw((size_t)chunk * rows * T * sizeof(float));
+        char* P = (char*)ex.raw((size_t)chunk * rows * T * es);
         if (!ex.dry) {
             for (int b0 = 0; b0 < X.B; b0 += chunk) {
                 const int nz = std::min(chunk, X.B - b0);
                 const size_t boff = (size_t)b0 * T * C * es;
                 // vT[z][c][t] = sum_k Wv[c][k] n[z][t][k]   (bias folded into the PV epilogue: softmax rows sum to 1)
                 gemm_nt(ex, a.v.w_for(dt), 0, (char*)n.p + boff, (long long)T * C, nullptr, vT, (long long)C * T, nz, C, T, C, 1.f, dt, dt);
-                gemm_nt(ex, (char*)q.p + boff, (long long)T * C, (char*)k.p + boff, (long long)T * C, nullptr, S, (long long)T * T, nz, T, T, C,
-                        1.0f / std::sqrt((float)C), dt, RS_F32);
-                ex.check(rs_softmax_rows_launch(S, P, dt, (long long)nz * T, T, T, T, ex.st), "softmax");
-                gemm_nt(ex, P, (long long)T * T, vT, (long long)C * T, a.v.bias, (char*)o.p + boff, (long long)T * C, nz, T, C, T, 1.f, dt, dt);
+                for (int r0 = 0; r0 < T; r0 += rows) {
+                    const int nr = std::min(rows, T - r0);   // (rows == T unless a single image is processed in row blocks)
+                    const size_t roff = boff + (size_t)r0 * C * es;
+                    gemm_nt(ex, (char*)q.p + roff, (long long)T * C, (char*)k.p + boff, (long long)T * C, nullptr, S, (long long)nr * T, nz, nr, T, C,
+                            1.0f / std::sqrt((float)C), dt, RS_F32);
+                    ex.check(rs_softmax_rows_launch(S, P, dt, (long long)nz * nr, T, T, T, ex.st), "softmax");
+                    gemm_nt(ex, P, (long long)nr * T, vT, (long long)C * T, a.v.bias, (char*)o.p + roff, (long long)T * C, nz, nr, C, T, 1.f, dt, dt);
+                }
             }
         }
         conv1(ex, a.proj, o, Y, &X);

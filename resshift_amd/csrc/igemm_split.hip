@@ -464,6 +464,15 @@ hipError_t launch_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t st
             default: return launch_cfg<TO, 64, 128, 4>(p, nz, st);
         }
     }
+    static const bool w4 = []() { const char* e = getenv("RS_SPLIT_W4"); return e && e[0] == '1'; }();   // A/B knob: 4 waves of 64 x BC/2
+    if (w4) {
+        switch (BC) {
+            case 64: break;
+            case 160: return launch_cfg<TO, 128, 160, 4>(p, nz, st);
+            case 192: return launch_cfg<TO, 128, 192, 4>(p, nz, st);
+            default: return launch_cfg<TO, 128, 128, 4>(p, nz, st);
+        }
+    }
     switch (BC) {
         case 64: return launch_cfg<TO, 128, 64, 8>(p, nz, st);
         case 160: return launch_cfg<TO, 128, 160, 8>(p, nz, st);

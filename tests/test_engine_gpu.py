@@ -533,3 +533,70 @@ def test_engine_rejects_inconsistent_sample_arguments(gpu):
         um0(torch.zeros(1, 3, 12, 16, device=gpu), [0], lq=torch.zeros(1, 3, 12, 16, device=gpu))
     with pytest.raises(RuntimeError, match="latent resolution"):
         um0(torch.zeros(1, 3, 16, 16, device=gpu), [0], lq=torch.zeros(1, 3, 32, 32, device=gpu))
+
+
+def _ae_once(tmp_path, tag, which, side, prec, budget=None):
+    import os
+    import subprocess
+    import sys
+
+    out = tmp_path / f"{tag}.pt"
+    env = dict(os.environ)
+    if budget is not None:
+        env["RS_ATTN_S_FLOATS"] = str(budget)
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run([sys.executable, os.path.join(here, "_ae_once.py"), str(out), which, str(side), prec], check=True, env=env, timeout=600)
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
+def test_ae_attention_in_query_row_blocks(gpu, tmp_path, prec):
+    """AttnBlock (ldm/modules/diffusionmodules/model.py:179-203) with the score matrix materialised one block of query rows at a
+    time (what bounds the scratch of the large tiles of the tiled path): bit-identical to the whole-matrix pass, and equal to the
+    oracle."""
+    up, ap, _, _ = H.CASES["tiny"]
+    _, asd = H.weights(up, ap)
+    whole = _ae_once(tmp_path, "whole", "tiny", 64, prec)
+    blocks = _ae_once(tmp_path, "blocks", "tiny", 64, prec, budget=128 * 256)    # T = 256 tokens -> two blocks of 128 rows
+    assert torch.equal(whole["z"], blocks["z"]) and torch.equal(whole["img"], blocks["img"])
+    g = torch.Generator().manual_seed(64)
+    img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    assert H.rel_err(blocks["z"], oc.vq_encode(asd, ap, img)) < TOL_NET[prec]
+
+
+def test_ae_attention_at_the_reference_tile_size(gpu, tmp_path):
+    """inference_resshift.py:149-161: --chop_size 256 with the x4 models means a 1024 x 1024 autoencoder input, i.e. T = 65 536
+    tokens in the mid-block attention (a 17 GB fp32 score matrix).  The engine processes it in blocks of query
+    rows; no CPU oracle can hold T x T, so the check is self-consistency across two different block sizes (row blocks are
+    independent; the block size only changes the GEMM tiling / split-K plan, i.e. the fp32 summation order) plus finiteness."""
+    a = _ae_once(tmp_path, "a", "realsr", 1024, "fp16")                            # default budget: 16384 rows per block
+    b = _ae_once(tmp_path, "b", "realsr", 1024, "fp16", budget=4096 * 65536)       # 4096 rows per block
+    assert tuple(a["z"].shape) == (1, 3, 256, 256) and torch.isfinite(a["z"]).all()
+    err = H.rel_err(a["z"], b["z"])
+    print(f"T = 65536 attention, 16384- vs 4096-row blocks: rel diff {err:.2e}")
+    assert err < 2e-3
+
+
+def test_tiled_path_at_the_reference_chop_size(gpu):
+    """sampler.py:186-208 with the reference's own x4 tile size (inference_resshift.py:149-161, --chop_size 256, stride 224): a
+    300 x 280 LR input -> four 256 x 256 LR tiles, each a 256 x 256 latent (UNet at 4x the constructed resolution: per-size
+    shift masks) and a T = 65 536 mid-block attention.  No CPU oracle at this size: shape, finiteness, range,
+    and determinism under noise_repeat are checked; parity of the same code path is covered at the small tile sizes above."""
+    from resshift_amd import ResShiftSampler
+    from resshift_amd.config import ConfigNode
+
+    up, ap, dp = H.realsr_params()
+    usd, asd = H.weights(up, ap)
+    cfg = ConfigNode(model=ConfigNode(target="models.unet.UNetModelSwin", ckpt_path=None, params=up),
+                     diffusion=ConfigNode(target="models.script_util.create_gaussian_diffusion", params=dp),
+                     autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=None, params=ap))
+    s = ResShiftSampler(cfg, sf=4, use_amp=True, chop_size=256, chop_stride=224, chop_bs=1, padding_offset=64, seed=7,
+                        state_dicts={"model": usd, "autoencoder": asd})
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(1, 3, 300, 280, generator=g) * 2 - 1).to(gpu)
+    out = s.sample_tiled(y, noise_repeat=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1, 3, 1200, 1120) and torch.isfinite(out).all() and out.abs().max().item() <= 1.0
+    again = s.sample_tiled(y, noise_repeat=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, again)
