@@ -32,6 +32,7 @@
 extern "C" {
 int rs_igemm_launch(const IGemmParams* p, int in_dt, int out_dt, int nz, hipStream_t st);
 int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt);
+int rs_igemm4_pick(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_groupnorm_launch(const GNParams* p, int dt, int apply_slabs, hipStream_t st);
 int rs_win_attn_launch(const WinAttnParams* p, int dt, hipStream_t st);
@@ -551,8 +552,32 @@ struct rs_engine {
     }
 
     // ---------------------------------------------------------------- ops
+    // parameter block of one implicit-GEMM conv launch (shared by conv() and the halo-kernel eligibility test)
+    static IGemmParams conv_params(const ConvW& w, const View& x, const View* x1, const View& y, int stride, int pad_t, int pad_l, int up,
+                                   int act, const View* res, float out_scale) {
+        const int C1 = x1 ? x1->C : 0;
+        IGemmParams p{};
+        p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = w.w_for(x.dt); p.bias = w.bias;
+        p.res = res ? res->p : nullptr; p.y = y.p;
+        p.C0 = x.C; p.C1 = C1; p.ld0 = x.ld; p.ld1 = x1 ? x1->ld : 0;
+        p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = up; p.Ho = y.H; p.Wo = y.W; p.KH = w.KH; p.KW = w.KW;
+        p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
+        p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
+        p.splitk = 1;
+        return p;
+    }
+    // true when this 3x3 conv runs on the halo kernel (igemm4.hip), which can apply a GroupNorm affine + SiLU to its input
+    // while the halo tile sits in LDS: the producer's raw output is read, the GroupNorm apply pass disappears
+    bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res) const {
+        if (w.direct || x.dt != RS_F16 || y.dt != RS_F16 || x.C != w.CinP) return false;
+        const int M = y.B * y.H * y.W;
+        if (rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * x.C, x.dt) > 1) return false;
+        const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
+        int tw, bc;
+        return rs_igemm4_pick(&p, x.dt, y.dt, 1, &tw, &bc) != 0;
+    }
     void conv(Exec& ex, const ConvW& w, const View& x, const View* x1, const View& y, int stride, int pad_t, int pad_l, int up,
-              int act, const View* res, float out_scale = 1.f) {
+              int act, const View* res, float out_scale = 1.f, const float* xcoef = nullptr, int xact = RS_ACT_NONE) {
         const int C1 = x1 ? x1->C : 0;
         // split-K for launches that cannot fill the chip (8x8 / 16x16 UNet levels): fp32 slabs live in the arena
         int splitk = 1;
@@ -585,14 +610,9 @@ struct rs_engine {
             if (res) { ex.err = -3; g_err = "direct conv has no residual path"; return; }
             ex.check(rs_direct_conv_launch(&p, x.dt, y.dt, ex.st), "direct_conv");
         } else {
-            IGemmParams p{};
-            p.x0 = x.p; p.x1 = x1 ? x1->p : nullptr; p.w = w.w_for(x.dt); p.bias = w.bias;
-            p.res = res ? res->p : nullptr; p.y = y.p;
-            p.C0 = x.C; p.C1 = C1; p.ld0 = x.ld; p.ld1 = x1 ? x1->ld : 0;
-            p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = up; p.Ho = y.H; p.Wo = y.W; p.KH = w.KH; p.KW = w.KW;
-            p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
-            p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
+            IGemmParams p = conv_params(w, x, x1, y, stride, pad_t, pad_l, up, act, res, out_scale);
             p.splitk = splitk; p.partial = partial;
+            p.xcoef = xcoef; p.xact = xact;
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
@@ -602,8 +622,24 @@ struct rs_engine {
         const hipError_t e = hipMemsetAsync(v.p, 0, (size_t)v.B * v.H * v.W * v.ld * rs_dtype_size(v.dt), ex.st);
         ex.check(e == hipSuccess ? 0 : -1, "memset");
     }
-    void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
-        conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res);
+    void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0, const float* xcoef = nullptr,
+               int xact = RS_ACT_NONE) {
+        conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res, 1.f, xcoef, xact);
+    }
+    // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
+    // halo kernel the GroupNorm only produces per-(image, channel) affine coefficients and the conv applies them to the RAW tensor
+    // in LDS (bit-identical to normalising first); otherwise normalise into a scratch tensor and convolve that
+    void gn_silu_conv3(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& Y, float eps, const float* film, const View* res) {
+        static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
+        if (fold && !ex.trace && halo_conv(w, X, Y, res)) {
+            float* coef = (float*)ex.raw((size_t)X.B * 2 * X.C * sizeof(float));
+            gn(ex, g, X, X, eps, RS_ACT_NONE, film, coef);
+            conv3(ex, w, X, Y, res, 0, coef, RS_ACT_SILU);
+            return;
+        }
+        View t = ex.T(X.B, X.H, X.W, X.C, X.dt);
+        gn(ex, g, X, t, eps, RS_ACT_SILU, film);
+        conv3(ex, w, t, Y, res);
     }
     void conv1(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
         conv(ex, w, x, nullptr, y, 1, 0, 0, 1, act, res);
@@ -635,39 +671,30 @@ struct rs_engine {
     // models/unet.py:186-206 (use_scale_shift_norm path); eps 1e-5 (basic_ops.py:96 default GroupNorm eps)
     void resblock(Exec& ex, const ResBlockW& r, const View& X, const View& Y, const float* film_row) {
         const size_t mk = ex.mark();
-        View t1 = ex.T(X.B, X.H, X.W, X.C, X.dt);
-        gn(ex, r.n1, X, t1, 1e-5f, RS_ACT_SILU);
-        ex.tr("gn1", t1);
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
-        conv3(ex, r.c1, t1, h1);
+        gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-5f, nullptr, nullptr);
         ex.tr("conv1", h1);
-        View t2 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
-        gn(ex, r.n2, h1, t2, 1e-5f, RS_ACT_SILU, film_row ? film_row + r.film_off : nullptr);
-        ex.tr("gn2film", t2);
+        const float* film = film_row ? film_row + r.film_off : nullptr;
         if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
             conv1(ex, r.skip, X, sk);
-            conv3(ex, r.c2, t2, Y, &sk);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-5f, film, &sk);
         } else {
-            conv3(ex, r.c2, t2, Y, &X);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-5f, film, &X);
         }
         ex.reset(mk);
     }
     // ldm/modules/diffusionmodules/model.py:129-149 (temb=None), GroupNorm eps 1e-6 (model.py:46-47)
     void resnet(Exec& ex, const ResBlockW& r, const View& X, const View& Y) {
         const size_t mk = ex.mark();
-        View t1 = ex.T(X.B, X.H, X.W, X.C, X.dt);
-        gn(ex, r.n1, X, t1, 1e-6f, RS_ACT_SILU);
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
-        conv3(ex, r.c1, t1, h1);
-        View t2 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
-        gn(ex, r.n2, h1, t2, 1e-6f, RS_ACT_SILU);
+        gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-6f, nullptr, nullptr);
         if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
             conv1(ex, r.skip, X, sk);
-            conv3(ex, r.c2, t2, Y, &sk);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-6f, nullptr, &sk);
         } else {
-            conv3(ex, r.c2, t2, Y, &X);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-6f, nullptr, &X);
         }
         ex.reset(mk);
     }
@@ -1469,6 +1496,31 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
     if (ms_out) *ms_out = ms / (float)std::max(1, reps);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (part) (void)hipFree(part);
+    return rc;
+}
+
+// GroupNorm-affine + SiLU + 3x3 conv on the halo kernel (igemm4.hip): x raw fp16 NHWC, coef_dev [B][2][Cin] fp32 (scale row,
+// shift row) or null, weights in the reference layout on the host; fails when the shape is not eligible for that kernel
+int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res, void* y,
+                       int B, int H, int W, int Cin, int Cout, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const size_t K = (size_t)9 * Cin, n = K * Cout;
+    std::vector<f16> o(n);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t) o[(size_t)co * K + (size_t)t * Cin + ci] = (f16)w_ref_host[((size_t)co * Cin + ci) * 9 + t];
+    void* wdev = dev_copy(o.data(), n * 2);
+    float* bias = bias_host ? (float*)dev_copy(bias_host, Cout * 4) : nullptr;
+    IGemmParams p{};
+    p.x0 = x; p.w = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin; p.B = B; p.Hs = H; p.Ws = W; p.up = 1; p.Ho = H; p.Wo = W;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = (int)K;
+    p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in;
+    int tw, bc, rc;
+    if (!rs_igemm4_pick(&p, RS_F16, RS_F16, 1, &tw, &bc)) rc = fail("shape is not eligible for the halo kernel");
+    else rc = rs_igemm_launch(&p, RS_F16, RS_F16, 1, st);
+    (void)hipStreamSynchronize(st);
+    if (wdev) (void)hipFree(wdev);
+    if (bias) (void)hipFree(bias);
     return rc;
 }
 

@@ -367,6 +367,8 @@ extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int*
 extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, int BP, int BC, int nz, hipStream_t st);
 extern "C" int rs_igemm3_pick(int M, int Cout, int Ktot, int in_dt, int nz, int splitk, int* BC);
 extern "C" int rs_igemm3_launch(const IGemmParams* pp, int out_dt, int BC, hipStream_t st);
+extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC);
+extern "C" int rs_igemm4_launch(const IGemmParams* pp, int TW, int BC, hipStream_t st);
 extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC);
 extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st);
 
@@ -421,6 +423,11 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     if (p.up != 1 && p.up != 2) return -2;
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
+    {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
+        int tw4 = 0, bc4 = 0;
+        if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, tw4, bc4, st);
+        if (p.xcoef) return -2;   // only the halo kernel applies an input transform: the caller must ask rs_igemm4_pick first
+    }
     if (in_dt == RS_F16S) return rs_igemm_split_launch(&p, out_dt, nz, st);   // split storage: igemm_split.hip (single source)
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one
     static const bool use_v2 = []() { const char* e = getenv("RS_IGEMM_V2"); return !(e && e[0] == '0'); }();

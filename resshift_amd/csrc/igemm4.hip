@@ -1,0 +1,329 @@
+// Halo-tile implicit GEMM for the 3x3 / stride-1 / pad-1 convolutions (fp16 storage), fourth generation.
+//
+// igemm2 / igemm3 gather the pixel operand once PER FILTER TAP: a 3x3 conv moves every input pixel nine times from L2 into
+// LDS, and the GroupNorm + SiLU in front of the conv (models/unet.py:128-147, ldm/modules/diffusionmodules/model.py:129-137)
+// needs its own read + write pass over the tensor because LDS-DMA data never passes through registers.  Here the loop nest
+// is turned inside out:
+//     for 64-channel chunk c:   halo tile (TH+2) x (TW+2) pixels x 64 channels  -> LDS  ONCE        (LDS-DMA)
+//                               [GroupNorm affine (+FiLM) + SiLU applied IN LDS, once per element]   (optional)
+//         for tap (ky,kx):      weight tile BC x 64 of W[:, tap, c]            -> LDS ring          (LDS-DMA)
+//                               MFMA: the pixel fragments are the SAME halo rows, read at offset ky*(TW+2)+kx
+//   * pixel traffic L2 -> LDS drops from 9 x 256 rows to (TH+2)(TW+2) = 396 rows per chunk (5.8 x less at TW = 64); the weight
+//     tile is amortised over 256 pixels (igemm2: 128);
+//   * the conv reads the RAW producer output: the GroupNorm apply pass (one read + one write of the whole tensor per
+//     GroupNorm) disappears, only the statistics pass remains.  The affine is applied exactly where gn_apply_kernel applies it
+//     (fp32 fma, SiLU, round to fp16), so results are bit-identical to the two-kernel path; halo rows outside the image stay
+//     exact zeros (the conv pads the NORMALISED tensor);
+//   * 128-byte LDS rows with the usual (chunk ^ row & 7) swizzle are conflict-free for ANY 16 consecutive rows, so the shifted
+//     fragment reads cost no more than the aligned ones.
+// Tile: 256 output pixels (TH x TW = 4 x 64 or 8 x 32, one image) x BC channels, 8 waves as 4 pixel-waves x 2 channel-waves
+// (wave tile 64 x BC/2), one workgroup per CU; LDS: 2 halo buffers (chunk c computes while chunk c+1 arrives, spread over the
+// taps) + 2 weight slots.  Epilogue as igemm2 (bias, activation, residual, fp16 transposition through LDS).
+#include "igemm_common.h"
+#include <type_traits>
+
+namespace {
+
+using namespace igemm_detail;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// NB: keep the LDS-DMA builtin inside a plain __device__ function (see igemm2.hip)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+// k-step 1 of a fragment address (chunk index ^ 4 = byte ^ 64), computed where it is used: as plain C++ the compiler hoists all
+// twelve variants out of the tap loop and the kernel spills
+__device__ __forceinline__ int xor64(int v) {
+    int r;
+    asm volatile("v_xor_b32 %0, 64, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+template <int TW, int BC>
+__global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
+    // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
+    // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
+    constexpr int TH = 256 / TW, HWD = (TW + 2 + 7) / 8 * 8, HROWS = (TH + 2) * HWD, HROWS_P = HROWS;
+    constexpr int XBUF = HROWS_P * 128;
+    constexpr int WSLOT = BC * 128;
+    constexpr int WBASE = 2 * XBUF;
+    constexpr int FP = 4, FC = BC / 32;
+    constexpr int XPIECES = HROWS_P / 8;        // 1 KB LDS-DMA pieces (8 halo rows x 128 B) of one chunk
+    constexpr int XPW = (XPIECES + 7) / 8;      // pieces per wave (wave w owns pieces w, w+8, ...)
+    constexpr int RWF = BC / 64, RWP = BC % 64, RW = RWF + (RWP ? 1 : 0);
+    constexpr int NCELL = (HROWS_P * 8 + 511) / 512;   // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
+    static_assert(XPW <= 8 && RWP % 8 == 0 && 2 * XBUF + 2 * WSLOT <= 160 * 1024, "tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wp = wave & 3, wc = wave >> 2;
+    const int rr = 8 * wave + (lane >> 3);
+    const int kcp = (lane & 7) ^ ((lane >> 3) & 7);    // source K-chunk of this lane (swizzle on the source side)
+    const bool wpart = !RWP || wave < RWP / 8;
+
+    // ---- tile decode: channel tiles of one pixel tile are adjacent (they share the halo in L2)
+    const int nby = (p.Cout + BC - 1) / BC;
+    const int txb_n = p.Wo / TW, tyb_n = p.Ho / TH;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = tile % nby; tile /= nby;
+    const int txb = tile % txb_n; tile /= txb_n;
+    const int tyb = tile % tyb_n;
+    const int b = tile / tyb_n;
+    const int n0 = nb * BC, y0 = tyb * TH, x0 = txb * TW;
+    const int Cin = p.C0;
+    // (scalars used inside the loops / lambdas are copied out of the by-value parameter block: a lambda capture of `p` itself
+    // makes the compiler park the whole struct in scratch memory, and scratch loads inside the K loop drain the DMA queue)
+    const float* const xcoef = p.xcoef;
+    const int xact = p.xact, Hs = p.Hs, Ws = p.Ws;
+
+    constexpr unsigned INV = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // Refill addresses are recomputed where they are used (a dozen VALU instructions per LDS-DMA piece): kept in registers across
+    // the K loop they push the kernel over 256 VGPRs, and a spilled value comes back through a scratch load - a VMEM access whose
+    // wait also drains the DMA queue.
+    const int Cout = p.Cout, Ktot = p.Ktot, ld0 = p.ld0;
+    auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w+8, ...)
+        if (wave + 8 * k >= XPIECES) return;                       // wave-uniform
+        const int hr = 8 * (wave + 8 * k) + (lane >> 3);
+        const int hy = hr / HWD, hx = hr - hy * HWD;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const unsigned cb = (unsigned)(c * 64 + kcp * 8);
+        const bool ok = hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && cb < (unsigned)Cin;
+        lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? (unsigned)((b * Hs + y) * Ws + x) * (unsigned)ld0 * 2u + cb * 2u : INV);
+    };
+    auto issue_w = [&](int s) {          // weight tile of stage s = (chunk s / 9, tap s % 9) -> slot s & 1
+        const int c = s / 9, tap = s - c * 9;
+        const unsigned cb = (unsigned)(c * 64 + kcp * 8);
+        const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u;
+        char* sbase = smem + WBASE + (s & 1) * WSLOT + (8 * wave) * 128;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            if (RWP && i == RW - 1 && !wpart) continue;
+            const int n = n0 + 64 * i + rr;
+            const bool ok = 64 * i + rr < BC && n < Cout && cb < (unsigned)Cin;
+            lds_dma16(rw, sbase + (64 * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * 2u + kb : INV);
+        }
+    };
+
+    // ---- fragment addressing
+    const int swz0 = ((lg ^ (lr & 7)) << 4), swz1 = (((4 + lg) ^ (lr & 7)) << 4);
+    const int la = (wc * (BC / 2) + lr) * 128;
+    int xfo[FP][3];   // LDS byte offset (k-step 0; k-step 1 = ^ 64) of (fragment j, lane) in the CURRENT halo buffer for kx = 0..2, ky = 0
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+        const int ty = TW == 64 ? wp : 2 * wp + (j >> 1);
+        const int tx = TW == 64 ? 16 * j : 16 * (j & 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hr = ty * HWD + tx + lr + kx;
+            xfo[j][kx] = hr * 128 + ((lg ^ (hr & 7)) << 4);
+        }
+    }
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- in-LDS GroupNorm (+FiLM) + activation of one halo chunk: thread t owns the 16-byte cells t, t+512, ...; their
+    // channel group (cell & 7) ^ (row & 7) is the same for all of them, so 16 coefficients per chunk stay in registers
+    const int cg = (tid & 7) ^ ((tid >> 3) & 7);
+    unsigned cell_in = 0;   // bit k: cell k of this thread is a pixel inside the image (the others must stay exact zeros)
+#pragma unroll
+    for (int k = 0; k < NCELL; ++k) {
+        const int hr = (tid >> 3) + 64 * k;
+        const int hy = hr / HWD, hx = hr - hy * HWD;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        if (hr < HROWS && hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) cell_in |= 1u << k;
+    }
+    auto apply = [&](int c, auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
+        const float* sc = xcoef + (long long)b * 2 * Cin + ch;
+        const f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
+        const f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        char* xb = smem + (c & 1) * XBUF + tid * 16;
+#pragma unroll
+        for (int k = 0; k < NCELL; ++k) {
+            if (!((cell_in >> k) & 1)) continue;
+            f16x8* cell = (f16x8*)(xb + k * 8192);
+            f16x8 v = *cell;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (f16)rs_act_t<ACT, true>(fmaf((float)v[e], a0[e], d0[e]));
+                v[4 + e] = (f16)rs_act_t<ACT, true>(fmaf((float)v[4 + e], a1[e], d1[e]));
+            }
+            *cell = v;
+        }
+    };
+
+    const int nch = (Cin + 63) / 64, nst = nch * 9;
+    // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
+    // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
+    // fragment register sets carried across the nine unrolled taps - igemm3's schedule - needs > 256 VGPRs here: 160 spilled
+    // registers, 557 instead of 810 TFLOP/s on the layer mix.)
+#pragma unroll
+    for (int k = 0; k < XPW; ++k) issue_x(0, k);
+    issue_w(0);
+    for (int c = 0; c < nch; ++c) {
+        const bool two = c * 64 + 64 <= Cin;     // full chunk: two k-steps of 32 channels (half chunk: one)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = c * 9 + tap;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tile s (and every halo piece issued before it) has landed
+            __builtin_amdgcn_s_barrier();
+            if (tap == 0) {
+                if (xcoef) {
+                    if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{});
+                    else apply(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (c > 0) {   // the fragment offsets move over to the other halo buffer
+                    const int flip = (c & 1) ? XBUF : -XBUF;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) xfo[j][q] += flip;
+                }
+            }
+            // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
+            if (c + 1 < nch && tap < XPW) issue_x(c + 1, tap);
+            if (s + 1 < nst) issue_w(s + 1);
+            const char* wb = smem + WBASE + (s & 1) * WSLOT + la;
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && !two) break;
+                const int sw = ks ? swz1 : swz0;
+                f16x8 a[FC], bf[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+
+    // ---------------------------------------------------------------- epilogue
+    f16* y = (f16*)p.y;
+    const f16* res = (const f16*)p.res;
+    // global pixel index of row r (0..63) of this wave's pixel tile
+    auto pixel = [&](int r) -> long long {
+        const int ty = TW == 64 ? wp : 2 * wp + (r >> 5);
+        const int tx = TW == 64 ? r : (r & 31);
+        return ((long long)b * p.Ho + y0 + ty) * p.Wo + x0 + tx;
+    };
+    constexpr int ROWB = (BC / 2) * 2 + 16;
+    char* stg = smem + wave * 64 * ROWB;
+    const bool res_ok = res != nullptr;
+    long long mres[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) mres[j] = pixel(j * 16 + lr) * p.ldres;
+    f32x4 bvs[FC];
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+        bvs[i] = p.bias ? *(const f32x4*)(p.bias + min(n, p.Cout - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto finish = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            f16x4 rv[FP];   // residual of this channel fragment (all FP loads in flight together)
+            if (res_ok) {
+                const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) rv[j] = *(const f16x4*)(res + mres[j] + nr);
+            }
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                f32x4 v = acc[i][j] * p.out_scale + bvs[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
+                if (res_ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[j][r];
+                }
+                f16x4 h;
+                h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
+                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
+    else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
+    else finish(std::integral_constant<int, RS_ACT_NONE>{});
+    __syncthreads();
+    constexpr int CPR = (BC / 2) / 8;
+    constexpr int NITEM = 64 * CPR;
+    for (int idx = lane; idx < NITEM; idx += 64) {
+        const int row = idx / CPR, c8 = idx - row * CPR;
+        const int n = n0 + wc * (BC / 2) + c8 * 8;
+        if (n >= p.Cout) continue;
+        *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+    }
+}
+
+template <int TW, int BC>
+hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
+    constexpr int TH = 256 / TW;
+    constexpr size_t lds = (size_t)2 * ((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128 + 2 * BC * 128;
+    const int tiles = p.B * (p.Ho / TH) * (p.Wo / TW) * ((p.Cout + BC - 1) / BC);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * 2, wb = (size_t)p.Cout * p.Ktot * 2;
+    if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+    hipLaunchKernelGGL((igemm4_kernel<TW, BC>), dim3(tiles), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Which launches take the halo kernel: fp16 in / out, one source, 3x3 stride 1 pad 1 without the folded upsample, planes that
+// tile by 4 x 64 or 8 x 32 output pixels, input channels in multiples of 32, output channels in multiples of 8 with a channel
+// tile of at most 192, no split-K / batching, enough tiles to fill the chip.  RS_IGEMM_V4=0 disables it.
+extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC) {
+    static const int on = []() { const char* e = getenv("RS_IGEMM_V4"); return e ? atoi(e) : 1; }();
+    static const int min_tiles = []() { const char* e = getenv("RS_IGEMM_V4_MINTILES"); return e ? atoi(e) : 192; }();
+    const IGemmParams& p = *pp;
+    if (!on || in_dt != RS_F16 || out_dt != RS_F16 || nz != 1 || p.splitk > 1 || p.C1 != 0) return 0;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
+    if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && (p.ldres % 4))) return 0;
+    const int tw = (p.Wo % 64 == 0) ? 64 : 32, th = 256 / tw;
+    if ((p.Wo % tw) || (p.Ho % th)) return 0;
+    auto waste = [&](int bc) { return ((p.Cout + bc - 1) / bc) * bc - p.Cout; };
+    int best = 128, bw = waste(128);
+    if (waste(160) < bw) { best = 160; bw = waste(160); }
+    if (waste(192) < bw) { best = 192; bw = waste(192); }
+    if (p.Cout < 96) return 0;
+    const long long tiles = (long long)p.B * (p.Ho / th) * (p.Wo / tw) * ((p.Cout + best - 1) / best);
+    if (tiles < min_tiles) return 0;
+    *TW = tw; *BC = best;
+    return 1;
+}
+
+extern "C" int rs_igemm4_launch(const IGemmParams* pp, int TW, int BC, hipStream_t st) {
+    hipError_t e;
+    if (TW == 64) e = BC == 160 ? launch4_cfg<64, 160>(*pp, st) : (BC == 192 ? launch4_cfg<64, 192>(*pp, st) : launch4_cfg<64, 128>(*pp, st));
+    else e = BC == 160 ? launch4_cfg<32, 160>(*pp, st) : (BC == 192 ? launch4_cfg<32, 192>(*pp, st) : launch4_cfg<32, 128>(*pp, st));
+    return e == hipSuccess ? 0 : -1;
+}

@@ -537,3 +537,41 @@ def test_gemm_nt_batched_and_softmax_split(gpu):
     o = ops.gemm_nt(p.view(nz, T, T), vt, bias=bias)
     torch.cuda.synchronize()
     _close(_unsplit(o), pr.view(nz, T, T) @ v.double() + bias.cpu().double(), 5e-6, "split PV")
+
+
+# ---------------------------------------------------------------- halo-tile 3x3 conv with the GroupNorm affine + SiLU fused in (igemm4.hip)
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, coef, res
+    (16, 64, 64, 160, 160, True, True),     # UNet 64x64 level: TW = 64, BC = 160, 2.5 channel chunks (half chunk at the end)
+    (16, 64, 64, 480, 160, True, False),    # 7.5 chunks
+    (32, 32, 32, 320, 320, True, True),     # 32x32 level: TW = 32 (8 x 32 pixel tiles), two channel tiles
+    (4, 128, 128, 128, 128, True, True),    # AE: BC = 128, 64-wide tiles of a 128-wide plane
+    (12, 64, 64, 192, 192, False, False),   # plain conv (no input transform), BC = 192
+    (3, 64, 192, 64, 256, True, True),      # non-square plane, one 64-channel chunk
+])
+def test_conv3x3_halo_with_fused_groupnorm_affine(gpu, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, use_coef, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xd = _nhwc(x, torch.float16, gpu)
+    xr = _ref_in(xd)
+    coef_d = None
+    if use_coef:
+        a = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+        d = torch.randn(B, Cin, generator=g) * 0.5
+        coef_d = torch.stack([a, d], 1).contiguous().to(gpu)                       # [B, 2, Cin]
+        xr = F.silu(xr * a[:, :, None, None] + d[:, :, None, None]).half().float()    # rounded where gn_apply_kernel rounds
+    ref = F.conv2d(xr, w.half().float(), bias, padding=1)
+    res_d = None
+    if use_res:
+        res_d = _nhwc(torch.randn(ref.shape, generator=g), torch.float16, gpu)
+        ref = ref + _ref_in(res_d)
+    y = ops.conv3x3_halo(xd, w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, TOL[torch.float16], f"halo conv {case}")
+    # and bit-identical to the generic implicit GEMM fed with the pre-normalised tensor? No: the K order differs (channel-major
+    # instead of tap-major); both are within the fp16 tolerance of the fp32 reference.
