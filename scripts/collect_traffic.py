@@ -4,7 +4,9 @@ counter unit = KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesce
 
     python scripts/collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 """
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from resshift_amd import build as _b  # kernel-source digest: bench.py ignores the file when the sources have changed since
 
 def total(path, counter):
     s = 0.0; n = 0
@@ -19,5 +21,6 @@ out = {"kernel_family": "igemm*_kernel + swin_mlp_kernel + win_attn_qkv_kernel",
        "fetch_bytes_per_launch": 2.0 * f * 1024 / max(1, nf), "write_bytes_per_launch": w * 1024 / max(1, nw),
        "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units, separate --pmc passes"}
 out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+out["kernel_source_digest"] = _b._digest()[:16]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

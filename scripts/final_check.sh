@@ -1,15 +1,22 @@
 #!/bin/bash
-# Round-end verification on the GPU box: tests, smoke, default bench, kernel trace and the two PMC traffic passes.
+# Round-end verification on the GPU box: tests, smoke, default bench, kernel traces of the fp16 and the parity policy, the two
+# PMC traffic passes of the fp16 bench, the other BASELINE configurations.
 # usage: scripts/final_check.sh <tag>   (outputs under gpurun_out/final_<tag>/)
-tag=${1:-r1}
+tag=${1:-r2}
 R=$(pwd); O=$R/gpurun_out/final_$tag; mkdir -p $O; export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
-timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-400 $O/bench.json
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o fp16 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass > $O/trace.log 2>&1)
-python scripts/rocpd_summary.py $(ls $O/trace/*.db | head -1) --top 16 > $O/kernel_trace.txt; head -24 $O/kernel_trace.txt
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-600 $O/bench.json
+for pol in fp16 parity; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$pol -o $pol -- python $R/bench.py --precision $pol --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass > $O/trace_$pol.log 2>&1)
+  python scripts/rocpd_summary.py $(ls $O/trace_$pol/*.db | head -1) --top 24 > $O/kernel_trace_$pol.txt; head -14 $O/kernel_trace_$pol.txt
+  rm -rf $O/trace_$pol
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass > $O/pmc_$c.log 2>&1)
 done
-python scripts/collect_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic_igemm.json
+python scripts/collect_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic_igemm_fp16.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE   # raw CSVs are large; the JSON carries the per-launch figures
+for cfg in journal faceir inpaint; do
+  timeout 300 python bench.py --config $cfg --steps 3 --warmup 1 --parity-images 2 --no-torch-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-300 $O/bench_$cfg.json
+done
