@@ -175,10 +175,11 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
                        int Ws, int Cin, int Cout, int KH, int KW, int stride, int pad, int Ho, int Wo, int up, int act, int in_prec,
                        int out_prec, int reps, float* ms_out, void* stream);
 /* halo-tile 3x3 conv with the GroupNorm affine + activation of its input fused in (igemm4.hip): y = conv3x3(act_in(x * coef[b][0][c]
- * + coef[b][1][c])) (+res); x / res / y fp16 NHWC device tensors, coef_dev [B][2][Cin] fp32 device (null: plain conv), act_in 0 / 2
- * (none / SiLU), weights [Cout][Cin][3][3] fp32 host.  Returns an error when the shape is not eligible for that kernel. */
+ * + coef[b][1][c])) (+res); x / res / y NHWC device tensors in `prec` storage (RS_PREC_F16 or RS_PREC_SPLIT), coef_dev [B][2][Cin]
+ * fp32 device (null: plain conv), act_in 0 / 2 (none / SiLU), weights [Cout][Cin][3][3] fp32 host.  Returns an error when the shape
+ * is not eligible for that kernel. */
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res,
-                       void* y, int B, int H, int W, int Cin, int Cout, void* stream);
+                       void* y, int B, int H, int W, int Cin, int Cout, int prec, void* stream);
 /* batched NT GEMM: y[z][m][n] = scale * sum_k a[z][m][k] * b[z][n][k]  (+bias[n]) */
 int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale,
                   int in_prec, int out_prec, void* stream);

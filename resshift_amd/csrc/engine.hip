@@ -304,7 +304,10 @@ struct rs_engine {
                         for (int ci = 0; ci < Cin; ++ci)
                             for (int t = 0; t < KH * KW; ++t) {
                                 f16 h, l;
-                                rs_split(w[((size_t)co * Cin + ci) * KH * KW + t], h, l);
+                                const float wv = w[((size_t)co * Cin + ci) * KH * KW + t];
+                                // (the halo kernel scales the hi fragment by 2^11 in fp16: exact below 32)
+                                if (!(std::fabs(wv) < 30.0f) && build_err.empty()) build_err = "split precision needs |weight| < 30: " + wkey;
+                                rs_split(wv, h, l);
                                 const size_t k = (size_t)t * CinP + ci;
                                 o[(size_t)co * 2 * K + k] = h;
                                 o[(size_t)co * 2 * K + K + k] = l;
@@ -569,7 +572,7 @@ struct rs_engine {
     // true when this 3x3 conv runs on the halo kernel (igemm4.hip), which can apply a GroupNorm affine + SiLU to its input
     // while the halo tile sits in LDS: the producer's raw output is read, the GroupNorm apply pass disappears
     bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res) const {
-        if (w.direct || x.dt != RS_F16 || y.dt != RS_F16 || x.C != w.CinP) return false;
+        if (w.direct || (x.dt != RS_F16 && x.dt != RS_F16S) || y.dt != x.dt || x.C != w.CinP) return false;
         const int M = y.B * y.H * y.W;
         if (rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * x.C, x.dt) > 1) return false;
         const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
@@ -1502,22 +1505,31 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
 // GroupNorm-affine + SiLU + 3x3 conv on the halo kernel (igemm4.hip): x raw fp16 NHWC, coef_dev [B][2][Cin] fp32 (scale row,
 // shift row) or null, weights in the reference layout on the host; fails when the shape is not eligible for that kernel
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res, void* y,
-                       int B, int H, int W, int Cin, int Cout, void* stream) {
+                       int B, int H, int W, int Cin, int Cout, int prec, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t K = (size_t)9 * Cin, n = K * Cout;
-    std::vector<f16> o(n);
+    if (prec != RS_F16 && prec != RS_F16S) return fail("halo kernel: fp16 or split storage");
+    const bool sp = prec == RS_F16S;
+    std::vector<f16> o(sp ? 2 * n : n);
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
-            for (int t = 0; t < 9; ++t) o[(size_t)co * K + (size_t)t * Cin + ci] = (f16)w_ref_host[((size_t)co * Cin + ci) * 9 + t];
-    void* wdev = dev_copy(o.data(), n * 2);
+            for (int t = 0; t < 9; ++t) {
+                const float wv = w_ref_host[((size_t)co * Cin + ci) * 9 + t];
+                if (!sp) { o[(size_t)co * K + (size_t)t * Cin + ci] = (f16)wv; continue; }
+                f16 h, l;
+                rs_split(wv, h, l);
+                o[(size_t)co * 2 * K + (size_t)t * Cin + ci] = h;
+                o[(size_t)co * 2 * K + K + (size_t)t * Cin + ci] = l;
+            }
+    void* wdev = dev_copy(o.data(), o.size() * 2);
     float* bias = bias_host ? (float*)dev_copy(bias_host, Cout * 4) : nullptr;
     IGemmParams p{};
     p.x0 = x; p.w = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin; p.B = B; p.Hs = H; p.Ws = W; p.up = 1; p.Ho = H; p.Wo = W;
     p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = (int)K;
     p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in;
     int tw, bc, rc;
-    if (!rs_igemm4_pick(&p, RS_F16, RS_F16, 1, &tw, &bc)) rc = fail("shape is not eligible for the halo kernel");
-    else rc = rs_igemm_launch(&p, RS_F16, RS_F16, 1, st);
+    if (!rs_igemm4_pick(&p, prec, prec, 1, &tw, &bc)) rc = fail("shape is not eligible for the halo kernel");
+    else rc = rs_igemm_launch(&p, prec, prec, 1, st);
     (void)hipStreamSynchronize(st);
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);

@@ -368,7 +368,7 @@ extern "C" int rs_igemm2_launch(const IGemmParams* pp, int in_dt, int out_dt, in
 extern "C" int rs_igemm3_pick(int M, int Cout, int Ktot, int in_dt, int nz, int splitk, int* BC);
 extern "C" int rs_igemm3_launch(const IGemmParams* pp, int out_dt, int BC, hipStream_t st);
 extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC);
-extern "C" int rs_igemm4_launch(const IGemmParams* pp, int TW, int BC, hipStream_t st);
+extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC, hipStream_t st);
 extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC);
 extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st);
 
@@ -425,7 +425,7 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
     {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
         int tw4 = 0, bc4 = 0;
-        if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, tw4, bc4, st);
+        if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, in_dt, tw4, bc4, st);
         if (p.xcoef) return -2;   // only the halo kernel applies an input transform: the caller must ask rs_igemm4_pick first
     }
     if (in_dt == RS_F16S) return rs_igemm_split_launch(&p, out_dt, nz, st);   // split storage: igemm_split.hip (single source)

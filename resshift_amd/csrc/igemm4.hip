@@ -19,6 +19,14 @@
 // Tile: 256 output pixels (TH x TW = 4 x 64 or 8 x 32, one image) x BC channels, 8 waves as 4 pixel-waves x 2 channel-waves
 // (wave tile 64 x BC/2), one workgroup per CU; LDS: 2 halo buffers (chunk c computes while chunk c+1 arrives, spread over the
 // taps) + 2 weight slots.  Epilogue as igemm2 (bias, activation, residual, fp16 transposition through LDS).
+//
+// SPLIT = true: the same kernel for split storage (RS_F16S: (hi, lo) fp16 pairs, common.h).  A chunk is 32 channels and an LDS
+// row holds [32 ch hi | 32 ch lo] - again 128 bytes / 8 sixteen-byte positions with the same swizzle, so the LDS image, the
+// LDS-DMA pieces and every fragment address are those of the fp16 kernel; position q of a row is fetched from the hi (q < 4) or
+// the lo plane of the pixel record / weight row.  What were the two k-steps of a stage are now the hi and the lo fragments of ONE
+// k-step: acc += (2^11 Wh).Xh + Wh.Xl + Wl.Xh (three MFMAs, ONE accumulator: the hi weight fragment is scaled by 2^11 with
+// v_pk_mul_f16 - exact for |w| < 32, checked when the weights are packed - instead of keeping a second accumulator set), and the
+// epilogue multiplies by 2^-11.  The GroupNorm pass joins, transforms and re-splits the pairs.
 #include "igemm_common.h"
 #include <type_traits>
 
@@ -41,8 +49,9 @@ __device__ __forceinline__ int xor64(int v) {
     return r;
 }
 
-template <int TW, int BC>
+template <int TW, int BC, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
+    constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
     // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
     // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
     constexpr int TH = 256 / TW, HWD = (TW + 2 + 7) / 8 * 8, HROWS = (TH + 2) * HWD, HROWS_P = HROWS;
@@ -93,21 +102,26 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const int hr = 8 * (wave + 8 * k) + (lane >> 3);
         const int hy = hr / HWD, hx = hr - hy * HWD;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const unsigned cb = (unsigned)(c * 64 + kcp * 8);
+        // source of LDS position (lane & 7) of this row = logical chunk kcp: fp16: channels 8 kcp ..; split: plane kcp >> 2
+        // (0 = hi, 1 = lo, `ld0` halfs further in the pixel record), channels 8 (kcp & 3) ..
+        const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
         const bool ok = hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && cb < (unsigned)Cin;
-        lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? (unsigned)((b * Hs + y) * Ws + x) * (unsigned)ld0 * 2u + cb * 2u : INV);
+        const unsigned pix = (unsigned)((b * Hs + y) * Ws + x);
+        const unsigned off = SPLIT ? pix * (unsigned)ld0 * 4u + (kcp >> 2) * (unsigned)ld0 * 2u + cb * 2u : pix * (unsigned)ld0 * 2u + cb * 2u;
+        lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? off : INV);
     };
     auto issue_w = [&](int s) {          // weight tile of stage s = (chunk s / 9, tap s % 9) -> slot s & 1
         const int c = s / 9, tap = s - c * 9;
-        const unsigned cb = (unsigned)(c * 64 + kcp * 8);
-        const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u;
+        const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
+        // weight rows: fp16 [K]; split [K hi | K lo]
+        const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u + (SPLIT ? (kcp >> 2) * (unsigned)Ktot * 2u : 0u);
         char* sbase = smem + WBASE + (s & 1) * WSLOT + (8 * wave) * 128;
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             if (RWP && i == RW - 1 && !wpart) continue;
             const int n = n0 + 64 * i + rr;
             const bool ok = 64 * i + rr < BC && n < Cout && cb < (unsigned)Cin;
-            lds_dma16(rw, sbase + (64 * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * 2u + kb : INV);
+            lds_dma16(rw, sbase + (64 * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + kb : INV);
         }
     };
 
@@ -143,6 +157,44 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         if (hr < HROWS && hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) cell_in |= 1u << k;
     }
+    // split storage: thread t owns, in rows (t >> 2) + 128 k, the position pair (t & 3, (t & 3) + 4) = the hi and the lo half (in
+    // swizzle-dependent order) of ONE 8-channel group
+    const int sp_hi = ((tid & 3) ^ ((tid >> 2) & 7)) < 4 ? (tid & 3) : (tid & 3) + 4;   // position holding the hi halves
+    const int sp_cg = ((tid & 3) ^ ((tid >> 2) & 7)) & 3;                                 // channel group inside the 32-channel chunk
+    unsigned sp_in = 0;
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+            const int hr = (tid >> 2) + 128 * k;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            if (hr < HROWS && hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) sp_in |= 1u << k;
+        }
+    }
+    auto apply_split = [&](int c, auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const float* sc = xcoef + (long long)b * 2 * Cin + c * 32 + sp_cg * 8;
+        const f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
+        const f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        char* xb = smem + (c & 1) * XBUF + (tid >> 2) * 128;
+#pragma unroll
+        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+            if (!((sp_in >> k) & 1)) continue;
+            f16x8* ch_ = (f16x8*)(xb + k * 16384 + sp_hi * 16);
+            f16x8* cl_ = (f16x8*)(xb + k * 16384 + (sp_hi ^ 4) * 16);
+            f16x8 vh = *ch_, vl = *cl_;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = fmaf(rs_join(vh[e], vl[e]), e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? d0[e & 3] : d1[e & 3]);
+                // SiLU with v_exp / v_rcp (1 ulp each): fp32-class, a fifth of the IEEE-division sequence
+                const float u = ACT == RS_ACT_SILU ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : t;
+                f16 hh, ll;
+                rs_split(u, hh, ll);
+                vh[e] = hh; vl[e] = ll;
+            }
+            *ch_ = vh; *cl_ = vl;
+        }
+    };
     auto apply = [&](int c, auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
@@ -164,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         }
     };
 
-    const int nch = (Cin + 63) / 64, nst = nch * 9;
+    const int nch = (Cin + KC - 1) / KC, nst = nch * 9;
     // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
     // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
     // fragment register sets carried across the nine unrolled taps - igemm3's schedule - needs > 256 VGPRs here: 160 spilled
@@ -173,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     for (int k = 0; k < XPW; ++k) issue_x(0, k);
     issue_w(0);
     for (int c = 0; c < nch; ++c) {
-        const bool two = c * 64 + 64 <= Cin;     // full chunk: two k-steps of 32 channels (half chunk: one)
+        const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = c * 9 + tap;
@@ -181,8 +233,13 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             __builtin_amdgcn_s_barrier();
             if (tap == 0) {
                 if (xcoef) {
-                    if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{});
-                    else apply(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    if constexpr (SPLIT) {
+                        if (xact == RS_ACT_SILU) apply_split(c, std::integral_constant<int, RS_ACT_SILU>{});
+                        else apply_split(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    } else {
+                        if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{});
+                        else apply(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
@@ -199,6 +256,29 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             if (s + 1 < nst) issue_w(s + 1);
             const char* wb = smem + WBASE + (s & 1) * WSLOT + la;
             const int ky = tap / 3, kx = tap % 3;
+            if constexpr (SPLIT) {
+                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
+                    bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                    al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks == 1 && !two) break;
@@ -218,8 +298,6 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
 
     // ---------------------------------------------------------------- epilogue
-    f16* y = (f16*)p.y;
-    const f16* res = (const f16*)p.res;
     // global pixel index of row r (0..63) of this wave's pixel tile
     auto pixel = [&](int r) -> long long {
         const int ty = TW == 64 ? wp : 2 * wp + (r >> 5);
@@ -227,85 +305,141 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         return ((long long)b * p.Ho + y0 + ty) * p.Wo + x0 + tx;
     };
     constexpr int ROWB = (BC / 2) * 2 + 16;
+    constexpr int CPR = (BC / 2) / 8;
+    constexpr int NITEM = 64 * CPR;
     char* stg = smem + wave * 64 * ROWB;
+    f16* y = (f16*)p.y;
+    const f16* res = (const f16*)p.res;
     const bool res_ok = res != nullptr;
     long long mres[FP];
 #pragma unroll
-    for (int j = 0; j < FP; ++j) mres[j] = pixel(j * 16 + lr) * p.ldres;
+    for (int j = 0; j < FP; ++j) mres[j] = pixel(j * 16 + lr) * p.ldres * (SPLIT ? 2 : 1);
     f32x4 bvs[FC];
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
         const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
         bvs[i] = p.bias ? *(const f32x4*)(p.bias + min(n, p.Cout - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto finish = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
+    if constexpr (SPLIT) {
+        // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
+        const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
+        const int act = p.act, ldres = p.ldres;
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
-            f16x4 rv[FP];   // residual of this channel fragment (all FP loads in flight together)
+            f16x4 rh[FP], rl[FP];
             if (res_ok) {
                 const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) rv[j] = *(const f16x4*)(res + mres[j] + nr);
+                for (int j = 0; j < FP; ++j) { rh[j] = *(const f16x4*)(res + mres[j] + nr); rl[j] = *(const f16x4*)(res + mres[j] + ldres + nr); }
             }
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
-                f32x4 v = acc[i][j] * p.out_scale + bvs[i];
+                f32x4 v = acc[i][j] * osc + bvs[i];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
-                if (res_ok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (act == RS_ACT_SILU) v[r] = rs_silu(v[r]); else if (act == RS_ACT_GELU) v[r] = rs_gelu(v[r]);
+                    if (res_ok) v[r] += rs_join(rh[j][r], rl[j][r]);
                 }
-                f16x4 h;
-                h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
-                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
-                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = v;
             }
         }
-    };
-    if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
-    else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
-    else finish(std::integral_constant<int, RS_ACT_NONE>{});
-    __syncthreads();
-    constexpr int CPR = (BC / 2) / 8;
-    constexpr int NITEM = 64 * CPR;
-    for (int idx = lane; idx < NITEM; idx += 64) {
-        const int row = idx / CPR, c8 = idx - row * CPR;
-        const int n = n0 + wc * (BC / 2) + c8 * 8;
-        if (n >= p.Cout) continue;
-        *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f16 hh, ll; rs_split(acc[i][j][r], hh, ll); h[r] = half ? ll : hh; }
+                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                }
+            __syncthreads();
+            for (int idx = lane; idx < NITEM; idx += 64) {
+                const int row = idx / CPR, c8 = idx - row * CPR;
+                const int n = n0 + wc * (BC / 2) + c8 * 8;
+                if (n >= p.Cout) continue;
+                *(uint4*)(y + pixel(row) * p.ldy * 2 + half * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+            }
+            __syncthreads();
+        }
+    } else {
+        auto finish = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                f16x4 rv[FP];   // residual of this channel fragment (all FP loads in flight together)
+                if (res_ok) {
+                    const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) rv[j] = *(const f16x4*)(res + mres[j] + nr);
+                }
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    f32x4 v = acc[i][j] * p.out_scale + bvs[i];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
+                    if (res_ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[j][r];
+                    }
+                    f16x4 h;
+                    h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
+                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
+        else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
+        else finish(std::integral_constant<int, RS_ACT_NONE>{});
+        __syncthreads();
+        for (int idx = lane; idx < NITEM; idx += 64) {
+            const int row = idx / CPR, c8 = idx - row * CPR;
+            const int n = n0 + wc * (BC / 2) + c8 * 8;
+            if (n >= p.Cout) continue;
+            *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+        }
     }
 }
 
-template <int TW, int BC>
+template <int TW, int BC, bool SPLIT>
 hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     constexpr int TH = 256 / TW;
     constexpr size_t lds = (size_t)2 * ((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128 + 2 * BC * 128;
     const int tiles = p.B * (p.Ho / TH) * (p.Wo / TW) * ((p.Cout + BC - 1) / BC);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * 2, wb = (size_t)p.Cout * p.Ktot * 2;
+    const size_t esz = SPLIT ? 4 : 2;
+    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * esz, wb = (size_t)p.Cout * p.Ktot * esz;
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
-    hipLaunchKernelGGL((igemm4_kernel<TW, BC>), dim3(tiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT>), dim3(tiles), dim3(512), lds, st, p);
     return hipGetLastError();
+}
+
+template <bool SPLIT>
+hipError_t launch4_t(const IGemmParams& p, int TW, int BC, hipStream_t st) {
+    if (TW == 64) return BC == 160 ? launch4_cfg<64, 160, SPLIT>(p, st) : (BC == 192 ? launch4_cfg<64, 192, SPLIT>(p, st) : launch4_cfg<64, 128, SPLIT>(p, st));
+    return BC == 160 ? launch4_cfg<32, 160, SPLIT>(p, st) : (BC == 192 ? launch4_cfg<32, 192, SPLIT>(p, st) : launch4_cfg<32, 128, SPLIT>(p, st));
 }
 
 }  // namespace
 
-// Which launches take the halo kernel: fp16 in / out, one source, 3x3 stride 1 pad 1 without the folded upsample, planes that
-// tile by 4 x 64 or 8 x 32 output pixels, input channels in multiples of 32, output channels in multiples of 8 with a channel
-// tile of at most 192, no split-K / batching, enough tiles to fill the chip.  RS_IGEMM_V4=0 disables it.
+// Which launches take the halo kernel: fp16 or split storage in / out (the same one), one source, 3x3 stride 1 pad 1 without the
+// folded upsample, planes that tile by 4 x 64 or 8 x 32 output pixels, input channels in multiples of 32, output channels in
+// multiples of 8 with a channel tile of at most 192, no split-K / batching, enough tiles to fill the chip.  RS_IGEMM_V4=0
+// disables it (RS_IGEMM_V4=1: fp16 only, 2: split only).
 extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC) {
-    static const int on = []() { const char* e = getenv("RS_IGEMM_V4"); return e ? atoi(e) : 1; }();
+    static const int on = []() { const char* e = getenv("RS_IGEMM_V4"); return e ? atoi(e) : 3; }();
     static const int min_tiles = []() { const char* e = getenv("RS_IGEMM_V4_MINTILES"); return e ? atoi(e) : 192; }();
     const IGemmParams& p = *pp;
-    if (!on || in_dt != RS_F16 || out_dt != RS_F16 || nz != 1 || p.splitk > 1 || p.C1 != 0) return 0;
+    if (in_dt != out_dt || nz != 1 || p.splitk > 1 || p.C1 != 0) return 0;
+    if (!((in_dt == RS_F16 && (on & 1)) || (in_dt == RS_F16S && (on & 2)))) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
     if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && (p.ldres % 4))) return 0;
     const int tw = (p.Wo % 64 == 0) ? 64 : 32, th = 256 / tw;
@@ -314,16 +448,14 @@ extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int 
     int best = 128, bw = waste(128);
     if (waste(160) < bw) { best = 160; bw = waste(160); }
     if (waste(192) < bw) { best = 192; bw = waste(192); }
-    if (p.Cout < 96) return 0;
+    if (p.Cout < 96 || (in_dt == RS_F16S && best == 192)) return 0;   // (split, BC = 192: over the register budget; no 3x3 conv of the models needs it)
     const long long tiles = (long long)p.B * (p.Ho / th) * (p.Wo / tw) * ((p.Cout + best - 1) / best);
     if (tiles < min_tiles) return 0;
     *TW = tw; *BC = best;
     return 1;
 }
 
-extern "C" int rs_igemm4_launch(const IGemmParams* pp, int TW, int BC, hipStream_t st) {
-    hipError_t e;
-    if (TW == 64) e = BC == 160 ? launch4_cfg<64, 160>(*pp, st) : (BC == 192 ? launch4_cfg<64, 192>(*pp, st) : launch4_cfg<64, 128>(*pp, st));
-    else e = BC == 160 ? launch4_cfg<32, 160>(*pp, st) : (BC == 192 ? launch4_cfg<32, 192>(*pp, st) : launch4_cfg<32, 128>(*pp, st));
+extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC, hipStream_t st) {
+    const hipError_t e = in_dt == RS_F16S ? launch4_t<true>(*pp, TW, BC, st) : launch4_t<false>(*pp, TW, BC, st);
     return e == hipSuccess ? 0 : -1;
 }

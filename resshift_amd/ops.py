@@ -65,16 +65,18 @@ def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw
 
 
 def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None):
-    """Halo-tile 3x3 conv (igemm4.hip): x [B,H,W,Cin] fp16 raw tensor, coef [B,2,Cin] fp32 device (GroupNorm affine: scale row,
-    shift row) applied with `act_in` (0 none / 2 SiLU) to x inside the kernel; returns [B,H,W,Cout] fp16."""
+    """Halo-tile 3x3 conv (igemm4.hip): x [B,H,W,Cin] raw tensor (fp16, or split storage as int32), coef [B,2,Cin] fp32 device
+    (GroupNorm affine: scale row, shift row) applied with `act_in` (0 none / 2 SiLU) to x inside the kernel; returns [B,H,W,Cout]
+    in the same storage."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w_ref.shape[0]
-    y = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.float16)
+    prec = _prec_of(x)
+    y = torch.empty(B, H, W, Cout, device=x.device, dtype=x.dtype)
     wh, wp = _hostf(w_ref)
     bh, bp = _hostf(bias) if bias is not None else (None, None)
     rc = lib.rs_op_conv3x3_halo(x.data_ptr(), coef.data_ptr() if coef is not None else None, act_in, wp, bp,
-                                res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout, _lib.current_stream_ptr())
+                                res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout, prec, _lib.current_stream_ptr())
     _lib.check(rc, "rs_op_conv3x3_halo")
     return y
 

@@ -575,3 +575,37 @@ def test_conv3x3_halo_with_fused_groupnorm_affine(gpu, case):
     _close(y.permute(0, 3, 1, 2), ref, TOL[torch.float16], f"halo conv {case}")
     # and bit-identical to the generic implicit GEMM fed with the pre-normalised tensor? No: the K order differs (channel-major
     # instead of tap-major); both are within the fp16 tolerance of the fp32 reference.
+
+
+@pytest.mark.parametrize("case", [
+    (16, 64, 64, 160, 160, True, True),     # 5 chunks of 32 channels
+    (32, 32, 32, 320, 320, True, True),     # TW = 32
+    (4, 128, 128, 128, 128, False, True),   # plain conv, BC = 128
+    (3, 64, 192, 96, 256, True, False),
+])
+def test_conv3x3_halo_split_storage(gpu, case):
+    """igemm4 on split storage: (hi, lo) pairs in, three MFMAs per product into one accumulator (the hi weight fragment scaled by
+    2^11), GroupNorm affine + SiLU applied to the joined value in LDS; float64 reference."""
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, use_coef, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xr = x.double()
+    coef_d = None
+    if use_coef:
+        a = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+        d = torch.randn(B, Cin, generator=g) * 0.5
+        coef_d = torch.stack([a, d], 1).contiguous().to(gpu)
+        xr = F.silu(xr * a.double()[:, :, None, None] + d.double()[:, :, None, None])
+    ref = F.conv2d(xr, w.double(), bias.double(), padding=1)
+    res_d = None
+    if use_res:
+        r = torch.randn(ref.shape, generator=g)
+        res_d = _split(r, gpu)
+        ref = ref + r.double()
+    y = ops.conv3x3_halo(_split(x, gpu), w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d)
+    torch.cuda.synchronize()
+    _close(_unsplit(y).permute(0, 3, 1, 2), ref, 3e-6, f"split halo conv {case}")
