@@ -96,6 +96,16 @@ def kernel_source_digest() -> str:
     return _b._digest()[:16]
 
 
+def per_kernel_rooflines(eng):
+    """MFMA-path kernel families of the engine's last (profiled) call: achieved TFLOP/s against the dense MFMA peak of the
+    arithmetic they run (split storage: three fp16 MFMAs per product -> 2500 / 3)"""
+    fam_peak = [MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"],
+                MFMA_PEAK_TFLOPS["fp32"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["fp16"]]
+    return [{"kernel": name, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
+             "frac": round(fl / (ms * 1e-3) / 1e12 / pk, 4), "ms_per_step": round(ms, 2), "launches_per_step": n}
+            for (name, fl, ms, n), pk in zip(eng.profile_families(), fam_peak) if n and ms > 0]
+
+
 def psnr_db(a, b, p2p):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else float(10 * np.log10(p2p * p2p / mse))
@@ -232,6 +242,8 @@ def main():
             "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(gflop_per_image * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
             "dominant_precision": dom,
         }
+        # per kernel family (north_star: "per-kernel achieved-fraction-of-roofline"): same hipEvent brackets, grouped
+        roofline["per_kernel"] = per_kernel_rooflines(eng)
         if st.get("gn_launches"):
             gbs = st["gn_bytes"] / (st["gn_ms"] * 1e-3) / 1e9 if st["gn_ms"] > 0 else 0.0
             roofline["groupnorm"] = {
@@ -293,6 +305,15 @@ def main():
             par = engine_parity(PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", pol)
             ms = timed(pol, 3)
             par.update({"ms_per_step": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 2), "steps_timed": 3})
+            if not args.no_profile_pass:
+                eng.profile_enable(True)
+                run(pol)
+                torch.cuda.synchronize()
+                st2 = eng.profile_get()
+                par["roofline_per_kernel"] = per_kernel_rooflines(eng)
+                if st2.get("gn_launches") and st2["gn_ms"] > 0:
+                    par["groupnorm_ms_per_step"] = round(st2["gn_ms"], 2)
+                eng.profile_enable(False)
             parity.append(par)
             log(f"parity policy: {par}")
         qualified = [p for p in parity if p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999]

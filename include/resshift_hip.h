@@ -155,6 +155,11 @@ long long rs_last_launch_count(rs_engine* e);
  * bracket so that the sum is the kernels' own duration. */
 int rs_profile_enable(rs_engine* e, int on);
 int rs_profile_get(rs_engine* e, double* out9);
+/* the same per kernel family of the MFMA path, in this order: halo conv fp16 (igemm4), halo conv split storage, implicit GEMM fp16
+ * (igemm2 / igemm3 / igemm), implicit GEMM split storage, implicit GEMM fp32 (exact), fused qkv + window attention + projection,
+ * fused Swin MLP.  out[3 f + 0] = algorithmic FLOPs, [3 f + 1] = kernel milliseconds, [3 f + 2] = launches; returns the number of
+ * families (7) or -1 when cap < 21. */
+int rs_profile_families(rs_engine* e, double* out, int cap);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
 int rs_debug_enable(rs_engine* e, int on);

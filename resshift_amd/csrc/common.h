@@ -84,6 +84,21 @@ __device__ __forceinline__ float rs_gelu_fast(float x) {
     const float hx = 0.5f * x;
     return fmaf(hx, g, hx);
 }
+// fp32-class GELU / SiLU without the IEEE division sequence and libm erff, for the split-precision kernels: v_rcp_f32 and
+// v_exp_f32 are 1 ulp each; erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute), i.e. the result is good to ~3e-7 of
+// |x| + 1.5e-7 - the class of the split pair itself (2^-23) - at a quarter of the VALU cost of rs_gelu
+__device__ __forceinline__ float rs_silu_acc(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float rs_gelu_acc(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(t, pl, 1.421413741f);
+    pl = fmaf(t, pl, -0.284496736f);
+    pl = fmaf(t, pl, 0.254829592f);
+    const float e = 1.0f - pl * t * __expf(-z * z);      // erf(|x| / sqrt 2)
+    const float hx = 0.5f * x;
+    return fmaf(copysignf(e, x), hx, hx);
+}
 // ACT is a compile-time constant here so that the element loops carry no per-value branches
 template <int ACT, bool FAST> __device__ __forceinline__ float rs_act_t(float x) {
     if constexpr (ACT == RS_ACT_GELU) return FAST ? rs_gelu_fast(x) : rs_gelu(x);
@@ -142,6 +157,11 @@ struct IGemmParams {
     // rounded to the storage type, is what the convolution sees (GroupNorm affine [B][2][C0] of GNParams::coef + SiLU)
     const float* xcoef;
     int xact;
+    // fused output statistics (halo kernel only): per-(image, pixel tile, channel) partial sum / sum of squares of the STORED
+    // output, [B][tiles per image][ystats_ld][2] floats, for the GroupNorm that consumes y (gn_apply_kernel, GNParams::cpartial):
+    // that GroupNorm then needs no statistics pass over the tensor.  Deterministic (fixed summation order, no atomics).
+    float* ystats;
+    int ystats_ld;
 };
 
 struct DirectConvParams {
@@ -163,6 +183,8 @@ struct GNParams {
     float eps; int act;
     float* coef;         // non-null: do not normalise; write the per-(image, channel) affine [B][2][C] (scale row, then shift row)
                          // so that a consumer kernel can apply y = x * scale + shift while it loads x (fused Swin kernels)
+    const float* cpartial;   // non-null: per-channel partial sums [B][S][cp_ld][2] written by the producing conv's epilogue
+    int cp_ld;               // (IGemmParams::ystats) replace `partial`; no statistics kernel runs
 };
 
 struct WinAttnParams {

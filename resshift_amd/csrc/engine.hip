@@ -62,9 +62,14 @@ struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
 struct View {
     void* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0, dt = RS_F16;
+    // optional per-channel partial statistics of this tensor, [B][stS][stld][2] floats (IGemmParams::ystats): set by whoever
+    // allocates the tensor when its producer is the halo conv kernel; the consuming GroupNorm then skips its statistics pass
+    float* st = nullptr; int stS = 0, stld = 0;
     long long pixels() const { return (long long)B * H * W; }
     View slice(int c0, int c) const {
-        View v = *this; v.p = (char*)p + (size_t)c0 * rs_dtype_chan_bytes(dt); v.C = c; return v;
+        View v = *this; v.p = (char*)p + (size_t)c0 * rs_dtype_chan_bytes(dt); v.C = c;
+        if (st) v.st = st + 2 * (size_t)c0;
+        return v;
     }
 };
 
@@ -149,8 +154,20 @@ struct Exec {
     double igemm_flops[3] = {0.0, 0.0, 0.0};  // per input precision (fp16, fp32, split)
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
+    // per kernel family of the MFMA path (rs_profile_families): algorithmic FLOPs, launches, and the family of every bracket
+    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_COUNT };
+    double fam_flops[F_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    long long fam_launches[F_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<unsigned char> fam_of;   // family of bracket k (profiling pass only)
+    void fam_note(int f, double flops) { fam_flops[f] += flops; ++fam_launches[f]; if (prof && prof->on) fam_of.push_back((unsigned char)f); }
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
         igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
+        {
+            int tw, bc;
+            const bool halo = rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw, &bc) != 0;
+            const int f = in_dt == RS_F16 ? (halo ? F_HALO16 : F_IGEMM16) : (in_dt == RS_F16S ? (halo ? F_HALO_SPLIT : F_IGEMM_SPLIT) : F_IGEMM32);
+            fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz);
+        }
         {
             const double isz = in_dt == RS_F16 ? 2.0 : 4.0, osz = out_dt == RS_F16 ? 2.0 : 4.0;
             const double src = (double)p.B * p.Hs * p.Ws * (double)(p.C0 + p.C1) * isz;
@@ -175,6 +192,7 @@ struct Exec {
     void win_attn_qkv(const WinAttnParams& p, int E) {
         const double M = (double)p.B * p.H * p.W;
         igemm_flops[0] += 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E;
+        fam_note(F_WINATTN, 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E + 2.0 * 2.0 * M * 64.0 * E);   // + QK^T and PV of the 64-token windows
         igemm_bytes += 2.0 * (M * E * (p.res ? 3.0 : 2.0) + (p.wproj ? 4.0 : 3.0) * E * E);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -194,6 +212,7 @@ struct Exec {
     void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                   int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0) {
         igemm_flops[0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
+        fam_note(F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD);
         igemm_bytes += 2.0 * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -224,6 +243,7 @@ struct rs_engine {
     long long last_launches = 0;
     Exec::Prof prof, prof_gn;
     double last_flops[3] = {0.0, 0.0, 0.0}, last_igemm_ms = 0.0, last_igemm_bytes = 0.0, last_gn_ms = 0.0, last_gn_bytes = 0.0;
+    double last_fam[Exec::F_COUNT][3] = {};   // flops, ms, launches per kernel family
     long long last_igemm_launches = 0, last_gn_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
@@ -616,6 +636,10 @@ struct rs_engine {
             IGemmParams p = conv_params(w, x, x1, y, stride, pad_t, pad_l, up, act, res, out_scale);
             p.splitk = splitk; p.partial = partial;
             p.xcoef = xcoef; p.xact = xact;
+            if (y.st) {   // statistics for the consuming GroupNorm: only the halo kernel's epilogue produces them
+                if (!x1 && stride == 1 && up == 1 && halo_conv(w, x, y, res)) { p.ystats = y.st; p.ystats_ld = y.stld; }
+                else { ex.err = -3; g_err = "output statistics requested from a conv that does not run on the halo kernel"; return; }
+            }
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
@@ -628,6 +652,15 @@ struct rs_engine {
     void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0, const float* xcoef = nullptr,
                int xact = RS_ACT_NONE) {
         conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res, 1.f, xcoef, xact);
+    }
+    // attach a statistics buffer to a tensor that is about to be produced by conv `w` from `x` (+res) IF that conv runs on the halo
+    // kernel (256-pixel tiles of one image: HW / 256 partial sets per image)
+    void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res) {
+        static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
+        const int HW = y.H * y.W;
+        if (!on || ex.trace || (HW % 256) || !halo_conv(w, x, y, res)) return;
+        y.stS = HW / 256; y.stld = y.ld;
+        y.st = (float*)ex.raw((size_t)y.B * y.stS * y.stld * 2 * sizeof(float));
     }
     // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
     // halo kernel the GroupNorm only produces per-(image, channel) affine coefficients and the conv applies them to the RAW tensor
@@ -663,7 +696,10 @@ struct rs_engine {
         GNParams p{};
         p.x = x.p; p.y = y.p; p.gamma = g.gamma; p.beta = g.beta; p.film = film; p.partial = partial;
         p.B = x.B; p.HW = HW; p.C = x.C; p.ldx = x.ld; p.ldy = y.ld; p.S = S; p.groups = 32; p.eps = eps; p.act = act; p.coef = coef;
-        ex.gn_bytes += (double)x.B * HW * x.C * (double)rs_dtype_size(x.dt) * (coef ? 1.0 : 2.0);
+        if (x.st) { p.cpartial = x.st; p.cp_ld = x.stld; p.S = x.stS; }   // per-channel partials from the producing conv: no statistics pass
+        // algorithmic bytes: normalise = read once + write once; coefficients only = read once, or nothing when the statistics
+        // come from the producing conv's epilogue
+        ex.gn_bytes += (double)x.B * HW * x.C * (double)rs_dtype_size(x.dt) * (coef ? (x.st ? 0.0 : 1.0) : 2.0);
         ++ex.gn_launches;
         hipEvent_t e0, e1;
         Exec::bracket(ex.prof_gn, ex.st, e0, e1);
@@ -675,6 +711,7 @@ struct rs_engine {
     void resblock(Exec& ex, const ResBlockW& r, const View& X, const View& Y, const float* film_row) {
         const size_t mk = ex.mark();
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
+        want_stats(ex, r.c1, X, h1, nullptr);   // conv1's epilogue leaves the statistics norm2 needs
         gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-5f, nullptr, nullptr);
         ex.tr("conv1", h1);
         const float* film = film_row ? film_row + r.film_off : nullptr;
@@ -691,6 +728,7 @@ struct rs_engine {
     void resnet(Exec& ex, const ResBlockW& r, const View& X, const View& Y) {
         const size_t mk = ex.mark();
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
+        want_stats(ex, r.c1, X, h1, nullptr);
         gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-6f, nullptr, nullptr);
         if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
@@ -1121,6 +1159,7 @@ struct rs_engine {
         last_igemm_bytes = r.igemm_bytes;
         last_igemm_ms = 0.0;
         last_gn_ms = 0.0; last_gn_bytes = r.gn_bytes; last_gn_launches = r.gn_launches;
+        for (int f = 0; f < Exec::F_COUNT; ++f) { last_fam[f][0] = r.fam_flops[f]; last_fam[f][1] = 0.0; last_fam[f][2] = (double)r.fam_launches[f]; }
         if (prof.on && prof.used) {
             // The event pair itself costs stream time (two marker packets bracket every launch): measure that cost with
             // empty pairs on the same stream and take it out, so that the per-launch figure is the kernel's own duration
@@ -1139,6 +1178,7 @@ struct rs_engine {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
                 last_igemm_ms += std::max(0.f, ms - overhead);
+                if (i / 2 < r.fam_of.size()) last_fam[r.fam_of[i / 2]][1] += std::max(0.f, ms - overhead);
             }
             for (size_t i = 0; i + 1 < prof_gn.used; i += 2) {
                 float ms = 0.f;
@@ -1243,6 +1283,15 @@ int rs_profile_get(rs_engine* e, double* out) {
     out[4] = e->last_igemm_bytes; out[5] = e->last_flops[2];
     out[6] = e->last_gn_ms; out[7] = (double)e->last_gn_launches; out[8] = e->last_gn_bytes;
     return 0;
+}
+
+// per kernel family of the MFMA path, in this order: halo conv fp16 (igemm4), halo conv split, implicit GEMM fp16 (igemm2 / igemm3 /
+// igemm), implicit GEMM split, implicit GEMM fp32, fused qkv + window attention + projection, fused Swin MLP:
+// out[3 f + 0] = algorithmic FLOPs, out[3 f + 1] = kernel ms (0 unless profiling was on), out[3 f + 2] = launches.  Returns the family count.
+int rs_profile_families(rs_engine* e, double* out, int cap) {
+    if (!e || !out || cap < 3 * Exec::F_COUNT) return -1;
+    for (int f = 0; f < Exec::F_COUNT; ++f) { out[3 * f] = e->last_fam[f][0]; out[3 * f + 1] = e->last_fam[f][1]; out[3 * f + 2] = e->last_fam[f][2]; }
+    return Exec::F_COUNT;
 }
 
 // ---- debug trace (tests only): record named intermediate activations of the next network call

@@ -320,6 +320,28 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
         bvs[i] = p.bias ? *(const f32x4*)(p.bias + min(n, p.Cout - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // per-channel statistics of the stored output for the consuming GroupNorm (IGemmParams::ystats): lane (lr, lg) accumulates its
+    // 4 channels of every channel fragment over its FP pixel fragments, then the 16 `lr` lanes are reduced with xor-shuffles
+    float* const ystats = p.ystats;
+    // (LDS: the staging tiles end below 8 * 64 * ROWB <= 106 KB; the partials sit behind them)
+    float* const sb = (float*)(smem + 8 * 64 * ROWB);
+    // wave-level sum of one (channel fragment, register) column over the 16 pixel lanes -> LDS
+    auto stats_put = [&](int i, int r, float a, float q) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (lr == 0) { sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
+    };
+    auto stats_out = [&]() {   // the four pixel-waves' partials -> one pair per channel of the tile -> global
+        __syncthreads();
+        if (tid < BC && n0 + tid < p.Cout) {
+            const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2 + 1]; }
+            float* dst = ystats + (((long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + tid) * 2;
+            dst[0] = a; dst[1] = q;
+        }
+    };
     if constexpr (SPLIT) {
         // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
@@ -342,7 +364,17 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                 }
                 acc[i][j] = v;
             }
+            if (ystats) {   // (the stored pair reproduces v to 2^-23)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = 0.f, q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) { a += acc[i][j][r]; q = fmaf(acc[i][j][r], acc[i][j][r], q); }
+                    stats_put(i, r, a, q);
+                }
+            }
         }
+        if (ystats) stats_out();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
                 f16x4 rv[FP];   // residual of this channel fragment (all FP loads in flight together)
                 if (res_ok) {
                     const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
@@ -386,13 +419,20 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                     f16x4 h;
                     h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
                     *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)h[r]; s1[r] += f; s2[r] = fmaf(f, f, s2[r]); }   // of the STORED value
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ystats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stats_put(i, r, s1[r], s2[r]);
                 }
             }
         };
         if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
         else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
         else finish(std::integral_constant<int, RS_ACT_NONE>{});
+        if (ystats) stats_out();
         __syncthreads();
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;

@@ -129,11 +129,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
     {
         const int g = tid % p.groups, sl = tid / p.groups;
         float a = 0.f, q = 0.f;
-        if (sl < nsl)
-            for (int s = sl; s < p.S; s += nsl) {
-                const float* in = p.partial + (((long long)b * p.S + s) * p.groups + g) * 2;
-                a += in[0]; q += in[1];
+        if (sl < nsl) {
+            if (p.cpartial) {   // per-channel partials of the producing conv's epilogue: channels -> group on the fly
+                for (int s = sl; s < p.S; s += nsl) {
+                    const float* in = p.cpartial + (((long long)b * p.S + s) * p.cp_ld + g * cpg) * 2;
+                    for (int c = 0; c < cpg; ++c) { a += in[2 * c]; q += in[2 * c + 1]; }
+                }
+            } else {
+                for (int s = sl; s < p.S; s += nsl) {
+                    const float* in = p.partial + (((long long)b * p.S + s) * p.groups + g) * 2;
+                    a += in[0]; q += in[1];
+                }
             }
+        }
         if (sl < nsl) { ps[(sl * p.groups + g) * 2] = a; ps[(sl * p.groups + g) * 2 + 1] = q; }
     }
     __syncthreads();
@@ -298,7 +306,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     // measured at B=32 (8-step bench, ms/step): fused up to 256 px 174.1, up to 1024 px 174.1, up to 4096 px 176.8 (too few,
     // too fat workgroups at 64x64) -> the 1024-thread variant stays off by default
     static const int fused_max = []() { const char* e = getenv("RS_GN_FUSED_MAXHW"); return e ? atoi(e) : 256; }();
-    if (fused_on && p.HW <= 256) {
+    if (fused_on && p.HW <= 256 && !p.cpartial) {
         constexpr int MAXI = 12;
         const int SC = gn_fused_slice<MAXI, 256>(p);
         if (SC > 0) {
@@ -308,7 +316,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
             else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI, 256>), g, dim3(256), 0, st, p, SC);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
-    } else if (fused_on && dt == RS_F16 && p.HW <= fused_max) {
+    } else if (fused_on && dt == RS_F16 && p.HW <= fused_max && !p.cpartial) {
         // 32x32 / 64x64 planes in fp16: 1024 threads hold up to 20 items (80 VGPRs) each; the tensor is read once instead of twice
         constexpr int MAXI = 20;
         const int SC = gn_fused_slice<MAXI, 1024>(p);
@@ -319,14 +327,15 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     }
     dim3 g1(p.S, p.B), g2(p.coef ? 1 : apply_slabs, p.B);
     const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
+    const bool need_stats = p.cpartial == nullptr;   // (else the producing conv's epilogue already left per-channel partial sums)
     if (dt == RS_F16) {
-        hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
     } else if (dt == RS_F16S) {
-        hipLaunchKernelGGL((gn_stats_kernel<h2s>), g1, dim3(256), 0, st, p);
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<h2s>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<h2s>), g2, dim3(256), lds, st, p);
     } else {
-        hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p);
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p);
         hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -236,3 +236,215 @@ extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1
     hipLaunchKernelGGL((swin_mlp_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same fusion for SPLIT storage (RS_F16S, common.h): y = res + fc2(GELU(fc1(x))) with every product formed from (hi, lo)
+// fp16 pairs - three MFMAs into ONE accumulator, the hi weight fragment scaled by 2^11 (igemm4.hip) - so that the parity-
+// qualified policy does not write and re-read the [M][768] hidden tensor (2 x 403 MB per Swin block at batch 32 on the 64 x 64
+// level) through two short-K split GEMMs.  One workgroup owns 128 tokens; a step handles 32 hidden units:
+//     S = X W1[h..h+32]^T  (K = E: six 32-channel chunks, token fragments (hi, lo) in registers)      36 MFMAs / wave
+//     P = split(GELU(S 2^-11 + b1)) -> LDS rows [32 hid hi | 32 hid lo] per token                      (16 KB)
+//     O += P W2[:, h..h+32]^T (K = 32)                                                                 36 MFMAs / wave
+// LDS rows are 128 bytes = [32 hi | 32 lo] halfs with the (position ^ row & 7) swizzle everywhere: W1 step [6 chunks][32 rows],
+// W2 step [192 rows], two slots each (96 KB) + P.  Waves: 4 token-waves x 2 (hidden / channel)-waves.
+namespace {
+
+struct MlpSplitParams {
+    const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
+    int M, ldx, ldres, ldy;
+    const float* xcoef;   // optional GroupNorm affine [B][2][E]: x is the raw tensor, normalised (joined value) while it is loaded
+    int HW;
+};
+
+template <int E, int HD>
+__global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p) {
+    constexpr int BP = 128, HS = 32, NST = HD / HS, KC = E / 32;     // tokens per workgroup, hidden units per step, steps, K chunks
+    constexpr int W1_SLOT = KC * HS * 128, W2_SLOT = E * 128;        // 24 KB each
+    constexpr int W1R = 0, W2R = 2 * W1_SLOT, PS = W2R + 2 * W2_SLOT;
+    constexpr int FC2 = E / 32;                                      // channel fragments per wave in GEMM2 (wave covers E/2 channels)
+    static_assert(E % 64 == 0 && HD % HS == 0 && PS + BP * 128 <= 160 * 1024, "shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wp = wave & 3, wc = wave >> 2;
+    const int kcp = (lane & 7) ^ ((lane >> 3) & 7);      // logical 16-byte chunk this lane fetches (source-side swizzle)
+    const int m0 = blockIdx.x * BP;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(HD * E * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(HD * E * 4), 0x00020000);
+    // weights of one step -> ring slot.  W1 (rows [E hi | E lo]): 6 chunks x 32 hidden rows = 24 one-KB pieces, 3 per wave;
+    // W2 (rows [HD hi | HD lo]): 192 channel rows = 24 pieces, 3 per wave
+    auto issue_w = [&](int t, int slot) {
+        const unsigned plane = (unsigned)(kcp >> 2), sub = (unsigned)(kcp & 3) * 8u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int piece = wave * 3 + q;                 // 0..23: chunk = piece / 4, row group = piece % 4
+            const int c = piece >> 2, rg = piece & 3;
+            const unsigned n = (unsigned)(t * HS + rg * 8 + (lane >> 3));
+            lds_dma16(r1, smem + W1R + slot * W1_SLOT + piece * 1024, (n * (unsigned)(2 * E) + plane * (unsigned)E + (unsigned)(c * 32) + sub) * 2u);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int piece = wave * 3 + q;                 // rows 8 piece ..
+            const unsigned n = (unsigned)(piece * 8 + (lane >> 3));
+            lds_dma16(r2, smem + W2R + slot * W2_SLOT + piece * 1024, (n * (unsigned)(2 * HD) + plane * (unsigned)HD + (unsigned)(t * HS) + sub) * 2u);
+        }
+    };
+    issue_w(0, 0);
+
+    // token fragments (MFMA B operand), hi and lo, straight from global memory: lane (lr, lg) holds channels 32 c + 8 lg .. of token lr
+    f16x8 xh[KC][2], xl[KC][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = min(m0 + wp * 32 + j * 16 + lr, p.M - 1);   // rows beyond M are clamped: their results are never stored
+        const f16* xr = p.x + (long long)m * p.ldx * 2 + lg * 8;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { xh[c][j] = *(const f16x8*)(xr + c * 32); xl[c][j] = *(const f16x8*)(xr + p.ldx + c * 32); }
+    }
+    if (p.xcoef) {   // GroupNorm (norm2) folded in: joined value * scale + shift, split again
+        const float* sc = p.xcoef + (long long)(m0 / p.HW) * 2 * E;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int c0 = c * 32 + lg * 8;
+            const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
+            const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f16 hh, ll;
+                    rs_split(fmaf(rs_join(xh[c][j][e], xl[c][j][e]), e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? d0[e & 3] : d1[e & 3]), hh, ll);
+                    xh[c][j][e] = hh; xl[c][j][e] = ll;
+                }
+        }
+    }
+    const int swh = (lg ^ (lr & 7)) << 4, swl = ((4 + lg) ^ (lr & 7)) << 4;   // hi / lo position of k-group lg in row lr (16-row aligned tiles)
+    f32x4 o[FC2][2];
+#pragma unroll
+    for (int i = 0; i < FC2; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int t = 0; t < NST; ++t) {
+        const int slot = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t have landed
+        __builtin_amdgcn_s_barrier();                        // ... everybody's; GEMM2 of step t-1 is finished everywhere (P and the other slot are free)
+        if (t + 1 < NST) issue_w(t + 1, slot ^ 1);
+        const f32x4 bv = *(const f32x4*)(p.b1 + t * HS + wc * 16 + lg * 4);
+        // ---- GEMM1: S[hidden 16 of this wave][32 tokens] over K = E (accumulator carries 2^11 x the sum)
+        f32x4 s_[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const char* pa = smem + W1R + slot * W1_SLOT + c * (HS * 128) + (wc * 16 + lr) * 128;
+            const f16x8 ah = *(const f16x8*)(pa + swh), al = *(const f16x8*)(pa + swl);
+            const f16x8 as = ah * (f16)RS_LO_SCALE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, xh[c][j], s_[j], 0, 0, 0);
+                s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[c][j], s_[j], 0, 0, 0);
+                s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[c][j], s_[j], 0, 0, 0);
+            }
+        }
+        // ---- bias + GELU -> (hi, lo) hidden activations P[token][32 hidden] in LDS (a lane holds hidden h..h+3 of token m)
+        {
+            const int h = wc * 16 + lg * 4;       // hidden index inside the step: hi position h >> 3, lo position 4 + (h >> 3)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = wp * 32 + j * 16 + lr;
+                f16x4 hv, lv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f16 hh, ll;
+                    rs_split(rs_gelu_acc(fmaf(s_[j][r], RS_LO_INV, bv[r])), hh, ll);
+                    hv[r] = hh; lv[r] = ll;
+                }
+                char* row = smem + PS + m * 128 + (h & 7) * 2;
+                *(f16x4*)(row + (((h >> 3) ^ (m & 7)) << 4)) = hv;
+                *(f16x4*)(row + (((4 + (h >> 3)) ^ (m & 7)) << 4)) = lv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- GEMM2: O[c][m] += W2[c][h..h+32] . P[m][..], wave tile (E/2) channels x 32 tokens, K = 32
+        {
+            const char* pa = smem + W2R + slot * W2_SLOT + (wc * (E / 2) + lr) * 128;
+            const char* pb = smem + PS + (wp * 32 + lr) * 128;
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { bh[j] = *(const f16x8*)(pb + j * 2048 + swh); bl[j] = *(const f16x8*)(pb + j * 2048 + swl); }
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) {
+                const f16x8 ah = *(const f16x8*)(pa + i * 2048 + swh), al = *(const f16x8*)(pa + i * 2048 + swl);
+                const f16x8 as = ah * (f16)RS_LO_SCALE;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], o[i][j], 0, 0, 0);
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], o[i][j], 0, 0, 0);
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], o[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
+
+    // ---- epilogue: 2^-11 O + b2 + residual, then the hi and the lo halves through LDS into 16-byte stores
+    constexpr int ROWB = (E / 2) * 2 + 16;
+    char* stg = smem + wave * 32 * ROWB;
+#pragma unroll
+    for (int i = 0; i < FC2; ++i) {
+        const int n = wc * (E / 2) + i * 16 + lg * 4;
+        const f32x4 bv = *(const f32x4*)(p.b2 + n);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v = o[i][j] * RS_LO_INV + bv;
+            if (p.res) {
+                const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres * 2;
+                const f16x4 rh = *(const f16x4*)(p.res + mr + n), rl = *(const f16x4*)(p.res + mr + p.ldres + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[r], rl[r]);
+            }
+            o[i][j] = v;
+        }
+    }
+    constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < FC2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f16 hh, ll; rs_split(o[i][j][r], hh, ll); h[r] = half ? ll : hh; }
+                *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+            }
+        __syncthreads();
+        for (int idx = lane; idx < NITEM; idx += 64) {
+            const int row = idx / CPR, c8 = idx - row * CPR;
+            const int m = m0 + wp * 32 + row;
+            if (m >= p.M) continue;
+            *(uint4*)(p.y + (long long)m * p.ldy * 2 + half * p.ldy + wc * (E / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// split storage: x / res / y tensors of (hi, lo) pairs, w1 / w2 packed [rows][K hi | K lo]
+extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
+                                        int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st) {
+    if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
+    if (xcoef && (HW <= 0 || HW % 128)) return -2;
+    MlpSplitParams p{};
+    p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
+    constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)swin_mlp_split_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((swin_mlp_split_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -279,6 +279,17 @@ class Engine:
         return {"flops_f16": out[0], "flops_f32": out[1], "igemm_ms": out[2], "igemm_launches": int(out[3]), "igemm_bytes": out[4],
                 "flops_split": out[5], "gn_ms": out[6], "gn_launches": int(out[7]), "gn_bytes": out[8]}
 
+    FAMILIES = ("igemm4_kernel<*, false> (halo 3x3 conv, fp16)", "igemm4_kernel<*, true> (halo 3x3 conv, split storage)",
+                "igemm2 / igemm3 / igemm_kernel (implicit GEMM, fp16)", "igemm_split_kernel (implicit GEMM, split storage)",
+                "igemm2 / igemm_kernel<float> (implicit GEMM, exact fp32)", "win_attn_qkv_kernel (fused qkv + window attention + proj)",
+                "swin_mlp_kernel (fused fc1 + GELU + fc2)")
+
+    def profile_families(self):
+        """per kernel family of the MFMA path: [(name, algorithmic FLOPs, kernel ms, launches)] of the last native call"""
+        out = (C.c_double * 21)()
+        n = self.lib.rs_profile_families(self._h, out, 21)
+        return [(self.FAMILIES[f], out[3 * f], out[3 * f + 1], int(out[3 * f + 2])) for f in range(max(0, n))]
+
     def debug_enable(self, on: bool = True):
         self.lib.rs_debug_enable(self._h, int(on))
 
