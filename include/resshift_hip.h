@@ -157,8 +157,8 @@ int rs_profile_enable(rs_engine* e, int on);
 int rs_profile_get(rs_engine* e, double* out9);
 /* the same per kernel family of the MFMA path, in this order: halo conv fp16 (igemm4), halo conv split storage, implicit GEMM fp16
  * (igemm2 / igemm3 / igemm), implicit GEMM split storage, implicit GEMM fp32 (exact), fused qkv + window attention + projection,
- * fused Swin MLP.  out[3 f + 0] = algorithmic FLOPs, [3 f + 1] = kernel milliseconds, [3 f + 2] = launches; returns the number of
- * families (7) or -1 when cap < 21. */
+ * fused Swin MLP, and the split-storage variants of those two.  out[3 f + 0] = algorithmic FLOPs, [3 f + 1] = kernel milliseconds,
+ * [3 f + 2] = launches; returns the number of families (9) or -1 when cap < 27. */
 int rs_profile_families(rs_engine* e, double* out, int cap);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
@@ -201,6 +201,9 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
  * (row-major fp16, device), fp32 biases; res may be null (models/swin_transformer.py:17-33,279) */
 int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
                    int M, int E, int HD, void* stream);
+/* the same on split storage (RS_PREC_SPLIT tensors of (hi, lo) fp16 pairs): weights packed [rows][K hi | K lo] fp16 on the device */
+int rs_op_swin_mlp_split(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
+                         int M, int E, int HD, void* stream);
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream);
 int rs_op_vq(const float* z, const float* codebook_dev, float* zq, int32_t* idx, long long N, int NE, int D, void* stream);
 int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out_prec, void* stream);

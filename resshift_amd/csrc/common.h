@@ -99,6 +99,31 @@ __device__ __forceinline__ float rs_gelu_acc(float x) {
     const float hx = 0.5f * x;
     return fmaf(copysignf(e, x), hx, hx);
 }
+// two values per lane at a time: the full-rate operations become v_pk_{mul,fma,add}_f32 (one issue slot for two fp32 results),
+// which is what keeps this epilogue work under the MFMA time of the fused split kernels
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rs_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rs_f32x2 rs_gelu_acc2(rs_f32x2 x) {
+    const rs_f32x2 one = {1.0f, 1.0f};
+    const rs_f32x2 z = rs_f32x2{fabsf(x.x), fabsf(x.y)} * 0.70710678118654752440f;
+    const rs_f32x2 d = __builtin_elementwise_fma(z, rs_f32x2{0.3275911f, 0.3275911f}, one);
+    const rs_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    rs_f32x2 pl = __builtin_elementwise_fma(t, rs_f32x2{1.061405429f, 1.061405429f}, rs_f32x2{-1.453152027f, -1.453152027f});
+    pl = __builtin_elementwise_fma(t, pl, rs_f32x2{1.421413741f, 1.421413741f});
+    pl = __builtin_elementwise_fma(t, pl, rs_f32x2{-0.284496736f, -0.284496736f});
+    pl = __builtin_elementwise_fma(t, pl, rs_f32x2{0.254829592f, 0.254829592f});
+    const rs_f32x2 q = pl * t;
+    const rs_f32x2 a = (x * x) * (-0.5f * 1.44269504088896340736f);       // -z^2 log2(e)
+    const rs_f32x2 ex = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const rs_f32x2 e = __builtin_elementwise_fma(-q, ex, one);               // erf(|x| / sqrt 2)
+    const rs_f32x2 hx = x * 0.5f;
+    const rs_f32x2 es = {copysignf(e.x, x.x), copysignf(e.y, x.y)};
+    return __builtin_elementwise_fma(es, hx, hx);
+}
+__device__ __forceinline__ void rs_split2(rs_f32x2 v, rs_f16x2& h, rs_f16x2& l) {
+    h = __builtin_convertvector(v, rs_f16x2);
+    l = __builtin_convertvector((v - __builtin_convertvector(h, rs_f32x2)) * RS_LO_SCALE, rs_f16x2);
+}
 // ACT is a compile-time constant here so that the element loops carry no per-value branches
 template <int ACT, bool FAST> __device__ __forceinline__ float rs_act_t(float x) {
     if constexpr (ACT == RS_ACT_GELU) return FAST ? rs_gelu_fast(x) : rs_gelu(x);

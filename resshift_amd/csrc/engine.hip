@@ -21,7 +21,9 @@
 #include "common.h"
 #include "../../include/resshift_hip.h"
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -44,6 +46,8 @@ int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st)
 int rs_win_attn_qkv_supported(int heads, int E);
 int rs_win_attn_qkv_launch(const WinAttnParams* p, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
+int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
+                             int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st);
 int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                        int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st);
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
@@ -155,18 +159,32 @@ struct Exec {
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     // per kernel family of the MFMA path (rs_profile_families): algorithmic FLOPs, launches, and the family of every bracket
-    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_COUNT };
-    double fam_flops[F_COUNT] = {0, 0, 0, 0, 0, 0, 0};
-    long long fam_launches[F_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_COUNT };
+    double fam_flops[F_COUNT] = {};
+    long long fam_launches[F_COUNT] = {};
     std::vector<unsigned char> fam_of;   // family of bracket k (profiling pass only)
-    void fam_note(int f, double flops) { fam_flops[f] += flops; ++fam_launches[f]; if (prof && prof->on) fam_of.push_back((unsigned char)f); }
+    // RS_PROF_SHAPES=1 (debugging aid): the profiling pass also keeps one "family M N K" tag per bracket and the engine prints
+    // the time per distinct shape to stderr
+    std::vector<std::string> tag_of;
+    std::vector<double> tag_flops;
+    void fam_note(int f, double flops, long long M = 0, int N = 0, int K = 0, int nz = 1) {
+        fam_flops[f] += flops; ++fam_launches[f];
+        if (prof && prof->on) {
+            fam_of.push_back((unsigned char)f);
+            static const bool shapes = getenv("RS_PROF_SHAPES") != nullptr;
+            if (shapes) {
+                char b[96]; snprintf(b, sizeof b, "f%d M=%lld N=%d K=%d z=%d", f, M, N, K, nz);
+                tag_of.emplace_back(b); tag_flops.push_back(flops);
+            }
+        }
+    }
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
         igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
         {
             int tw, bc;
             const bool halo = rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw, &bc) != 0;
             const int f = in_dt == RS_F16 ? (halo ? F_HALO16 : F_IGEMM16) : (in_dt == RS_F16S ? (halo ? F_HALO_SPLIT : F_IGEMM_SPLIT) : F_IGEMM32);
-            fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz);
+            fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz, p.M, p.Cout, p.Ktot, nz);
         }
         {
             const double isz = in_dt == RS_F16 ? 2.0 : 4.0, osz = out_dt == RS_F16 ? 2.0 : 4.0;
@@ -210,10 +228,11 @@ struct Exec {
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
     void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
-                  int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0) {
-        igemm_flops[0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
-        fam_note(F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD);
-        igemm_bytes += 2.0 * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
+                  int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0, int dt = RS_F16) {
+        const int sp = dt == RS_F16S;
+        igemm_flops[sp ? 2 : 0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
+        fam_note(sp ? F_SWINMLP_S : F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD);
+        igemm_bytes += (sp ? 4.0 : 2.0) * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && prof->on) {
@@ -225,7 +244,8 @@ struct Exec {
             e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
             (void)hipEventRecord(e0, st);
         }
-        check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, st), "swin_mlp");
+        if (sp) check(rs_swin_mlp_split_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, st), "swin_mlp_split");
+        else check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, st), "swin_mlp");
         if (e1) (void)hipEventRecord(e1, st);
     }
 };
@@ -795,11 +815,11 @@ struct rs_engine {
             View e3;
             // fp16 storage: one fused launch, the [M][4E] hidden tensor never reaches HBM (swin_mlp.hip); RS_MLP_FUSED=0 or a
             // small token count (RS_MLP_FUSED_MINM) keep the two GEMMs
-            static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 1; }();
+            static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 3; }();   // bit 0: fp16, bit 1: split storage
             static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 16384; }();   // (8192 tokens: 32 us fused vs 14 + 15 us apart)
             const int Mtok = X.B * X.H * X.W;
-            const bool fuse_mlp = mlp_fused && X.dt == RS_F16 && rs_swin_mlp_supported(E, s.fc1.Cout) && s.fc2.Cout == E && Mtok >= mlp_minm &&
-                                  s.fc1.wh && s.fc2.wh;
+            const bool fuse_mlp = mlp_fused && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
+                                  s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.w_for(X.dt) && s.fc2.w_for(X.dt);
             const bool fold2 = fuse_mlp && gn_fold && !ex.trace && (X.H * X.W) % 128 == 0;
             View n2;
             float* coef2 = nullptr;
@@ -808,8 +828,9 @@ struct rs_engine {
             if (fuse_mlp) {
                 e3 = ex.T(X.B, X.H, X.W, E, X.dt);
                 if (!ex.dry) {
-                    if (fold2) ex.swin_mlp(e2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, e2.ld, e2.ld, e3.ld, E, s.fc1.Cout, coef2, X.H * X.W);
-                    else ex.swin_mlp(n2.p, s.fc1.wh, s.fc1.bias, s.fc2.wh, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout);
+                    const void* w1 = s.fc1.w_for(X.dt); const void* w2 = s.fc2.w_for(X.dt);
+                    if (fold2) ex.swin_mlp(e2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, e2.ld, e2.ld, e3.ld, E, s.fc1.Cout, coef2, X.H * X.W, X.dt);
+                    else ex.swin_mlp(n2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout, nullptr, 0, X.dt);
                 }
             } else {
                 View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
@@ -1179,6 +1200,23 @@ struct rs_engine {
                 (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
                 last_igemm_ms += std::max(0.f, ms - overhead);
                 if (i / 2 < r.fam_of.size()) last_fam[r.fam_of[i / 2]][1] += std::max(0.f, ms - overhead);
+            }
+            if (!r.tag_of.empty()) {
+                std::map<std::string, std::array<double, 3>> agg;
+                for (size_t i = 0; i + 1 < prof.used && i / 2 < r.tag_of.size(); i += 2) {
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
+                    auto& a = agg[r.tag_of[i / 2]];
+                    a[0] += std::max(0.f, ms - overhead); a[1] += 1.0; a[2] += r.tag_flops[i / 2];
+                }
+                std::vector<std::pair<double, std::string>> rows;
+                for (auto& kv : agg) {
+                    char b[200]; snprintf(b, sizeof b, "%-40s n=%4.0f  %8.3f ms  %7.1f us/launch  %7.1f TF/s", kv.first.c_str(), kv.second[1], kv.second[0],
+                                          1e3 * kv.second[0] / kv.second[1], kv.second[2] / (kv.second[0] * 1e-3) / 1e12);
+                    rows.emplace_back(-kv.second[0], b);
+                }
+                std::sort(rows.begin(), rows.end());
+                for (auto& rw : rows) fprintf(stderr, "[shapes] %s\n", rw.second.c_str());
             }
             for (size_t i = 0; i + 1 < prof_gn.used; i += 2) {
                 float ms = 0.f;
@@ -1670,6 +1708,12 @@ int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const
                    int M, int E, int HD, void* stream) {
     const int rc = rs_swin_mlp_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, (hipStream_t)stream);
     if (rc) fail("swin_mlp launch rejected the shape (fp16, E = 192, HD = 768 only)");
+    return rc;
+}
+int rs_op_swin_mlp_split(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
+                         int M, int E, int HD, void* stream) {
+    const int rc = rs_swin_mlp_split_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, (hipStream_t)stream);
+    if (rc) fail("swin_mlp_split launch rejected the shape (split storage, E = 192, HD = 768 only)");
     return rc;
 }
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream) {

@@ -49,7 +49,9 @@ __device__ __forceinline__ int xor64(int v) {
     return r;
 }
 
-template <int TW, int BC, bool SPLIT>
+// ABL (builds with -DRS_SPLIT_ABLATE only, RS_IGEMM4_ABL=n selects): timing ablations, results wrong: bit 0 = no weight loads
+// after the first two stages, bit 1 = no halo loads after chunk 0, bit 2 = no MFMAs
+template <int TW, int BC, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
     // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                 }
             }
             // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
-            if (c + 1 < nch && tap < XPW) issue_x(c + 1, tap);
-            if (s + 1 < nst) issue_w(s + 1);
+            if (c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
+            if (s + 1 < nst && (!(ABL & 1) || s < 1)) issue_w(s + 1);
             const char* wb = smem + WBASE + (s & 1) * WSLOT + la;
             const int ky = tap / 3, kx = tap % 3;
             if constexpr (SPLIT) {
@@ -291,7 +293,10 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FP; ++j) {
+                        if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
     }
@@ -458,6 +463,19 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+#ifdef RS_SPLIT_ABLATE
+    if constexpr (!SPLIT && BC == 160) {
+        static const int abl = []() { const char* v = getenv("RS_IGEMM4_ABL"); return v ? atoi(v) : 0; }();
+#define RS_ABL4_CASE(A)                                                                                                              \
+    if (abl == A) {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, A>), dim3(tiles), dim3(512), lds, st, p);                                    \
+        return hipGetLastError();                                                                                                      \
+    }
+        RS_ABL4_CASE(1) RS_ABL4_CASE(2) RS_ABL4_CASE(3) RS_ABL4_CASE(4) RS_ABL4_CASE(7)
+#undef RS_ABL4_CASE
+    }
+#endif
     hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT>), dim3(tiles), dim3(512), lds, st, p);
     return hipGetLastError();
 }

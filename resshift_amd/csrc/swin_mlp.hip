@@ -247,6 +247,13 @@ extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1
 //     O += P W2[:, h..h+32]^T (K = 32)                                                                 36 MFMAs / wave
 // LDS rows are 128 bytes = [32 hi | 32 lo] halfs with the (position ^ row & 7) swizzle everywhere: W1 step [6 chunks][32 rows],
 // W2 step [192 rows], two slots each (96 KB) + P.  Waves: 4 token-waves x 2 (hidden / channel)-waves.
+// Measured at 131 072 tokens: 337 us (229 TFLOP/s algorithmic = 688 TFLOP/s of MFMA work, 29 % MFMA-busy) against 215 + 109 us
+// + the hidden tensor's round trip for the two separate split GEMMs.  Three other schedules of the same tile were measured
+// and dropped (scripts/mlp_split_time.py): GEMM1 of step t+1 issued ahead of the activation math of step t (W1 one step ahead of
+// W2), one barrier per step with a double-buffered P, and that one cut into six MFMA / VALU blocks by scheduling fences:
+// 343 - 363 us, all at the 256-register limit.  With 8 waves per CU (one workgroup: 112 KB of LDS) the kernel is bound by the
+// latency chain barrier -> LDS fragment reads -> MFMA -> activation -> LDS, not by any single pipe: timing ablations without
+// the weight DMA, without the activation math and without the MFMAs each remove only 12 - 28 %.
 namespace {
 
 struct MlpSplitParams {
@@ -351,16 +358,13 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int m = wp * 32 + j * 16 + lr;
-                f16x4 hv, lv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f16 hh, ll;
-                    rs_split(rs_gelu_acc(fmaf(s_[j][r], RS_LO_INV, bv[r])), hh, ll);
-                    hv[r] = hh; lv[r] = ll;
-                }
+                // (two values per lane at a time: v_pk_fma_f32 / v_pk_mul_f32 / v_cvt_pk_f16_f32)
+                rs_f16x2 h0, l0, h1, l1;
+                rs_split2(rs_gelu_acc2(__builtin_elementwise_fma(rs_f32x2{s_[j][0], s_[j][1]}, rs_f32x2{RS_LO_INV, RS_LO_INV}, rs_f32x2{bv[0], bv[1]})), h0, l0);
+                rs_split2(rs_gelu_acc2(__builtin_elementwise_fma(rs_f32x2{s_[j][2], s_[j][3]}, rs_f32x2{RS_LO_INV, RS_LO_INV}, rs_f32x2{bv[2], bv[3]})), h1, l1);
                 char* row = smem + PS + m * 128 + (h & 7) * 2;
-                *(f16x4*)(row + (((h >> 3) ^ (m & 7)) << 4)) = hv;
-                *(f16x4*)(row + (((4 + (h >> 3)) ^ (m & 7)) << 4)) = lv;
+                *(f16x4*)(row + (((h >> 3) ^ (m & 7)) << 4)) = f16x4{h0.x, h0.y, h1.x, h1.y};
+                *(f16x4*)(row + (((4 + (h >> 3)) ^ (m & 7)) << 4)) = f16x4{l0.x, l0.y, l1.x, l1.y};
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

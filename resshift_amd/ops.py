@@ -139,16 +139,30 @@ def window_attention_qkv(x, wqkv, bqkv, table, heads, shift, wproj=None, bproj=N
     return out
 
 
+def split_pack_rows(w):
+    """[rows, K] float weights -> the split-storage operand [rows][K hi | K lo] fp16 (hi = fp16(w), lo = fp16((w - hi) 2^11))"""
+    w = w.detach().float()
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    return torch.cat([hi, lo], dim=1).contiguous()
+
+
 def swin_mlp(x, w1, b1, w2, b2, res=None):
-    """x: [M, E] fp16 device; w1 [HD, E], w2 [E, HD] (any float dtype, rounded to fp16 like the engine's weights)."""
+    """x: [M, E] fp16 (or split storage as int32) device; w1 [HD, E], w2 [E, HD] (any float dtype; rounded to fp16, or to
+    (hi, lo) pairs for split storage, like the engine's weights)."""
     lib = _lib.load()
     M, E = x.shape
     HD = w1.shape[0]
-    w1d, w2d = w1.to(x.device, torch.float16).contiguous(), w2.to(x.device, torch.float16).contiguous()
+    split = x.dtype == torch.int32
+    if split:
+        w1d, w2d = split_pack_rows(w1).to(x.device), split_pack_rows(w2).to(x.device)
+    else:
+        w1d, w2d = w1.to(x.device, torch.float16).contiguous(), w2.to(x.device, torch.float16).contiguous()
     b1d, b2d = b1.to(x.device, torch.float32).contiguous(), b2.to(x.device, torch.float32).contiguous()
-    y = torch.empty(M, E, device=x.device, dtype=torch.float16)
-    rc = lib.rs_op_swin_mlp(x.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), res.data_ptr() if res is not None else None,
-                            y.data_ptr(), M, E, HD, _lib.current_stream_ptr())
+    y = torch.empty(M, E, device=x.device, dtype=x.dtype)
+    fn = lib.rs_op_swin_mlp_split if split else lib.rs_op_swin_mlp
+    rc = fn(x.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), res.data_ptr() if res is not None else None,
+            y.data_ptr(), M, E, HD, _lib.current_stream_ptr())
     _lib.check(rc, "swin_mlp")
     return y
 

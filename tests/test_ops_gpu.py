@@ -366,6 +366,29 @@ def test_swin_mlp_fused(gpu, M, use_res):
     _close(y, ref, 2e-3, f"swin mlp M={M}")
 
 
+@pytest.mark.parametrize("M,use_res", [(128, True), (1000, True), (16384, False)])
+def test_swin_mlp_fused_split(gpu, M, use_res):
+    """swin_mlp_split_kernel: the same fusion on (hi, lo) fp16 pairs, three MFMAs per product, fp32-class result: against
+    torch fp64 on the unrounded operands (hidden activations are (hi, lo) pairs as well: nothing is rounded to fp16)."""
+    from resshift_amd import ops
+
+    E, HD = 192, 768
+    g = torch.Generator().manual_seed(M + 5)
+    x = torch.randn(M, E, generator=g)
+    w1 = torch.randn(HD, E, generator=g) / math.sqrt(E)
+    w2 = torch.randn(E, HD, generator=g) / math.sqrt(HD)
+    b1, b2 = torch.randn(HD, generator=g) * 0.3, torch.randn(E, generator=g) * 0.3
+    res = torch.randn(M, E, generator=g) if use_res else None
+    xs = ops.convert(x.to(gpu), ops.SPLIT)
+    rs_ = ops.convert(res.to(gpu), ops.SPLIT) if use_res else None
+    y = ops.convert(ops.swin_mlp(xs, w1, b1, w2, b2, rs_), ops.F32)
+    torch.cuda.synchronize()
+    ref = F.gelu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    if use_res:
+        ref = ref + res.double()
+    _close(y, ref.float(), 3e-6, f"split swin mlp M={M}")
+
+
 @pytest.mark.parametrize("hw,shift", [((16, 16), 0), ((16, 16), 4), ((8, 8), 0), ((24, 16), 4), ((64, 64), 4)])
 def test_window_attention_fused_qkv(gpu, hw, shift):
     """win_attn_qkv_kernel: qkv Linear (swin_transformer.py:85,121) + window attention in one launch, against the torch
