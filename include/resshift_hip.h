@@ -131,6 +131,11 @@ int rs_axpbypcz(const float* x, const float* z, const float* n, float* y, float 
 int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C, int H, int W, int h0, int w0, int th, int tw,
                        void* stream);
 int rs_tile_finalize(float* acc, const float* count, int B, int C, int H, int W, void* stream);
+/* fp32 planes [planes][H][W] -> [planes][Ho][Wo]: out[i][j] = scale * in[refl(h0 + i)][refl(w0 + j)], refl(i) = i < n ? i : 2(n-1) - i.
+ * The host mirror's data movement on the device: reflect padding of the LQ batch (sampler.py:130-138), the tile crop of the
+ * tiled path (utils/util_image.py:946-952; the window must then lie inside the plane) and the latent scaling of
+ * encode_first_stage (models/gaussian_diffusion.py:514).  -2 when the window overhangs the plane by a full plane size or more. */
+int rs_window_copy(const float* in, float* out, long long planes, int H, int W, int h0, int w0, int Ho, int Wo, float scale, void* stream);
 
 /* uint8 pre / post processing on the device.
  * rs_u8_to_input:  interleaved uint8 [B,H,W,C] -> planar fp32 [B,C,H,W] in [-1,1]  ((v/255 - 0.5)/0.5; replaces

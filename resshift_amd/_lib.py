@@ -86,6 +86,7 @@ SIGNATURES = {
     "rs_axpbypcz": (_I, [_P, _P, _P, _P, _F, _F, _F, _LL, _P]),
     "rs_tile_accumulate": (_I, [_P, _P, _P] + [_I] * 8 + [_P]),
     "rs_tile_finalize": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "rs_window_copy": (_I, [_P, _P, _LL, _I, _I, _I, _I, _I, _I, _F, _P]),
     "rs_u8_to_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "rs_output_to_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rs_arena_bytes": (_SZ, [_P]),
@@ -152,3 +153,21 @@ def current_stream_ptr() -> int:
     if torch.cuda.is_available():
         return int(torch.cuda.current_stream().cuda_stream)
     return 0
+
+
+def window_copy(x, h0=0, w0=0, ho=None, wo=None, scale=1.0, out=None):
+    """fp32 device tensor [..., H, W] -> [..., ho, wo] window starting at (h0, w0), reflected past the bottom / right edge and
+    multiplied by `scale` (rs_window_copy: reflect padding, tile crops and the latent scaling of the host mirror)."""
+    import torch
+
+    if not x.is_cuda:
+        raise RuntimeError("window_copy needs a device tensor: the host mirror does not fall back to CPU arithmetic")
+    x = x.to(torch.float32).contiguous()
+    H, W = x.shape[-2:]
+    ho = H if ho is None else ho
+    wo = W if wo is None else wo
+    planes = x.numel() // (H * W)
+    if out is None:
+        out = torch.empty(*x.shape[:-2], ho, wo, device=x.device, dtype=torch.float32)
+    check(load().rs_window_copy(x.data_ptr(), out.data_ptr(), planes, H, W, h0, w0, ho, wo, float(scale), current_stream_ptr()), "rs_window_copy")
+    return out

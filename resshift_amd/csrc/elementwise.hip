@@ -254,6 +254,24 @@ static int convert_from(const TI* src, void* dst, int dst_dt, int C, long long n
     else return -2;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// out[pl][i][j] = scale * in[pl][refl(h0 + i, H)][refl(w0 + j, W)] on fp32 planes, refl(i, n) = i < n ? i : 2 (n - 1) - i.
+// One kernel for the data movement the host mirror needs around the networks: bottom / right reflect padding of the LQ batch
+// (sampler.py:130-138, F.pad mode 'reflect'), the tile crop of the tiled path (util_image.py:946-952) and the latent scaling
+// of encode_first_stage (gaussian_diffusion.py:514).
+__global__ void window_copy_kernel(const float* in, float* out, long long planes, int H, int W, int h0, int w0, int Ho, int Wo, float scale) {
+    const long long n = planes * Ho * Wo;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(g % Wo);
+        const long long t = g / Wo;
+        const int i = (int)(t % Ho);
+        const long long pl = t / Ho;
+        int y = h0 + i, x = w0 + j;
+        y = y < H ? y : 2 * (H - 1) - y;
+        x = x < W ? x : 2 * (W - 1) - x;
+        out[g] = scale * in[(pl * H + y) * W + x];
+    }
+}
+
 extern "C" {
 
 int rs_nchw_to_nhwc_launch(const float* in, void* out, int out_dt, int B, int C, int HW, int ldo, int coff, float scale, hipStream_t st) {
@@ -323,6 +341,15 @@ int rs_tile_accumulate(float* acc, float* count, const float* tile, int B, int C
     if (h0 < 0 || w0 < 0 || h0 + th > H || w0 + tw > W) return -2;
     const long long n = (long long)B * C * th * tw;
     hipLaunchKernelGGL(tile_accumulate_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, acc, count, tile, B, C, H, W, h0, w0, th, tw);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int rs_window_copy(const float* in, float* out, long long planes, int H, int W, int h0, int w0, int Ho, int Wo, float scale, void* stream) {
+    // (one reflection at most, as torch: the window may overhang the plane by less than its size)
+    if (planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || h0 < 0 || w0 < 0 || h0 + Ho > 2 * H - 1 || w0 + Wo > 2 * W - 1 || h0 >= H || w0 >= W)
+        return -2;
+    const long long n = planes * Ho * Wo;
+    hipLaunchKernelGGL(window_copy_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, out, planes, H, W, h0, w0, Ho, Wo, scale);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -17,6 +17,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from .autoencoder import VQModelTorch
 from .engine import F16, F32, Engine, parse_precision
 from .unet import UNetModelSwin, params_version
@@ -166,7 +167,7 @@ class ResShiftDiffusion:
         if up_sample and self.sf != 1:
             y = eng.bicubic(y, self.sf)
         z = first_stage_model.encode(y, prec=self._prec(self.precision_encode))
-        return z * self.scale_factor if self.scale_factor != 1.0 else z
+        return _lib.window_copy(z, scale=self.scale_factor) if self.scale_factor != 1.0 else z   # (one fp32 multiply on the device)
 
     def decode_first_stage(self, z_sample, first_stage_model=None, consistencydecoder=None):
         """gaussian_diffusion.py:474-498"""
@@ -174,7 +175,9 @@ class ResShiftDiffusion:
             raise NotImplementedError("consistency decoder is out of scope")
         if first_stage_model is None:
             return z_sample
-        return first_stage_model.decode(z_sample * (1.0 / self.scale_factor), prec=self._prec(self.precision_decode))
+        if self.scale_factor != 1.0:
+            z_sample = _lib.window_copy(z_sample, scale=1.0 / self.scale_factor)
+        return first_stage_model.decode(z_sample, prec=self._prec(self.precision_decode))
 
     def p_mean_variance(self, model, x_t, y, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """gaussian_diffusion.py:234-307 (START_X).  `t`: [B] tensor of equal indices."""

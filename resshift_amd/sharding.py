@@ -14,7 +14,8 @@ from typing import Callable, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
+
+from . import _lib
 
 
 def init_distributed() -> Tuple[int, int]:
@@ -90,8 +91,11 @@ def gather_images(local: torch.Tensor, n_global: int, rank: int, world: int) -> 
 
 
 def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
-    """F.pad(..., mode='reflect') on the bottom/right (sampler.py:130-138)."""
-    return F.pad(x, pad=(0, pad_w, 0, pad_h), mode="reflect")
+    """F.pad(..., mode='reflect') on the bottom/right (sampler.py:130-138), on the device (rs_window_copy)."""
+    H, W = x.shape[-2:]
+    if pad_h >= H or pad_w >= W:
+        raise ValueError("reflect padding must be smaller than the padded side (as torch.nn.functional.pad requires)")
+    return _lib.window_copy(x, 0, 0, H + pad_h, W + pad_w)
 
 
 BLOB_CACHE_MAGIC = b"RSBLOB03"   # bump when the packed layout (csrc/engine.hip weight builder) changes

@@ -57,7 +57,12 @@ class TileSplitter:
         self.count_pchs += len(cur)
         ps, sf = self.pch_size, self.sf
         H, W = self.im_ori.shape[2:]
-        pch = torch.cat([self.im_ori[:, :, h0:h0 + ps, w0:w0 + ps] for h0, w0 in cur], dim=0)
+        # tile crops on the device (rs_window_copy), stacked along the batch axis like the reference's torch.cat of slices
+        B0, C0 = self.im_ori.shape[:2]
+        th, tw = min(ps, H), min(ps, W)
+        pch = torch.empty(len(cur) * B0, C0, th, tw, device=self.im_ori.device, dtype=torch.float32)
+        for k, (h0, w0) in enumerate(cur):
+            _lib.window_copy(self.im_ori, h0, w0, th, tw, out=pch[k * B0:(k + 1) * B0])
         # a side that is <= pch_size yields a shorter tile (the slice clamps, as the reference's does, util_image.py:946-952):
         # the canvas window is clamped likewise (the reference's slice ASSIGNMENT clamps it, :962-968)
         index_infos = [[h0 * sf, min(h0 + ps, H) * sf, w0 * sf, min(w0 + ps, W) * sf] for h0, w0 in cur]

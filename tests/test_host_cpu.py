@@ -317,3 +317,12 @@ def test_kernel_register_budgets():
                  "gn_fused_kernelIDF16_Li12ELi256E", "gn_apply_kernelIDF16_", "gn_stats_kernelIDF16_"):
         for k in find(name):
             assert k["vgpr_count"] <= 256 and k["vgpr_spill_count"] == 0, (name, k)
+
+
+def test_host_mirror_data_movement_needs_the_device():
+    """reflect padding / tile crops / latent scaling run in rs_window_copy: a CPU tensor is an error, never a silent torch fallback"""
+    import pytest
+    from resshift_amd import sharding
+
+    with pytest.raises(RuntimeError, match="device tensor"):
+        sharding.reflect_pad(torch.zeros(1, 3, 8, 8), 2, 2)

@@ -632,3 +632,25 @@ def test_conv3x3_halo_split_storage(gpu, case):
     y = ops.conv3x3_halo(_split(x, gpu), w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d)
     torch.cuda.synchronize()
     _close(_unsplit(y).permute(0, 3, 1, 2), ref, 3e-6, f"split halo conv {case}")
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 3, 40, 28), (24, 20)), ((1, 1, 17, 64), (15, 0)), ((3, 3, 64, 64), (0, 0)), ((1, 3, 5, 7), (4, 6))])
+def test_window_copy_reflect_pad_crop_scale(gpu, shape, pad):
+    """rs_window_copy against torch: bottom / right reflect padding (sampler.py:130-138 F.pad mode 'reflect'), a tile crop and the
+    latent scaling - all bit-exact (pure data movement / one fp32 multiply)."""
+    from resshift_amd import _lib, sharding
+
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    ph, pw = pad
+    got = sharding.reflect_pad(x.to(gpu), ph, pw)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), F.pad(x, pad=(0, pw, 0, ph), mode="reflect"))
+    H, W = shape[-2:]
+    h0, w0, th, tw = H // 3, W // 4, H - H // 3 - 1, W - W // 4
+    got = _lib.window_copy(x.to(gpu), h0, w0, th, tw)
+    assert torch.equal(got.cpu(), x[..., h0:h0 + th, w0:w0 + tw])
+    got = _lib.window_copy(x.to(gpu), scale=0.18215)
+    assert torch.equal(got.cpu(), x * torch.tensor(0.18215, dtype=torch.float32))
+    with pytest.raises(RuntimeError):
+        _lib.window_copy(x.to(gpu), 0, 0, 2 * H, W)      # more than one reflection: rejected, as torch rejects it
