@@ -49,6 +49,9 @@ __device__ __forceinline__ int xor64(int v) {
     return r;
 }
 
+#ifdef RS_SPLIT_ABLATE
+__device__ long long g_ig4_clk[4 * 8192];   // per workgroup: cycle counter at kernel start / K loop start / K loop end / kernel end (ablate builds)
+#endif
 // ABL (builds with -DRS_SPLIT_ABLATE only, RS_IGEMM4_ABL=n selects): timing ablations, results wrong: bit 0 = no weight loads
 // after the first two stages, bit 1 = no halo loads after chunk 0, bit 2 = no MFMAs
 template <int TW, int BC, bool SPLIT, int ABL = 0>
@@ -60,15 +63,22 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     constexpr int XBUF = HROWS_P * 128;
     constexpr int WSLOT = BC * 128;
     constexpr int WBASE = 2 * XBUF;
+    // weight ring: three slots wherever 160 KB allow it (tile s+2 is requested at stage s and has two stages to land: with two
+    // slots the L2 round trip of tile s+1 - ~1 us under load against a 1.1 us stage - shows up as 8 - 14 % of the kernel time,
+    // profiles/r2_igemm4_ablation.txt); (TW = 64, BC = 160) and BC = 192 keep two
+    constexpr int NSLOT = (2 * XBUF + 3 * WSLOT <= 160 * 1024) ? 3 : 2;
     constexpr int FP = 4, FC = BC / 32;
     constexpr int XPIECES = HROWS_P / 8;        // 1 KB LDS-DMA pieces (8 halo rows x 128 B) of one chunk
     constexpr int XPW = (XPIECES + 7) / 8;      // pieces per wave (wave w owns pieces w, w+8, ...)
     constexpr int RWF = BC / 64, RWP = BC % 64, RW = RWF + (RWP ? 1 : 0);
     constexpr int NCELL = (HROWS_P * 8 + 511) / 512;   // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
-    static_assert(XPW <= 8 && RWP % 8 == 0 && 2 * XBUF + 2 * WSLOT <= 160 * 1024, "tile");
+    static_assert(XPW <= 8 && RWP % 8 == 0 && 2 * XBUF + NSLOT * WSLOT <= 160 * 1024, "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef RS_SPLIT_ABLATE
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x] = clock64();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int wp = wave & 3, wc = wave >> 2;
@@ -112,12 +122,12 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const unsigned off = SPLIT ? pix * (unsigned)ld0 * 4u + (kcp >> 2) * (unsigned)ld0 * 2u + cb * 2u : pix * (unsigned)ld0 * 2u + cb * 2u;
         lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? off : INV);
     };
-    auto issue_w = [&](int s) {          // weight tile of stage s = (chunk s / 9, tap s % 9) -> slot s & 1
+    auto issue_w = [&](int s, int slot) {   // weight tile of stage s = (chunk s / 9, tap s % 9) -> ring slot s % NSLOT (passed in)
         const int c = s / 9, tap = s - c * 9;
         const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
         // weight rows: fp16 [K]; split [K hi | K lo]
         const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u + (SPLIT ? (kcp >> 2) * (unsigned)Ktot * 2u : 0u);
-        char* sbase = smem + WBASE + (s & 1) * WSLOT + (8 * wave) * 128;
+        char* sbase = smem + WBASE + slot * WSLOT + (8 * wave) * 128;
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             if (RWP && i == RW - 1 && !wpart) continue;
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             *ch_ = vh; *cl_ = vl;
         }
     };
-    auto apply = [&](int c, auto act_tag) {
+    auto apply = [&](int c, auto act_tag) __attribute__((always_inline)) {   // (not inlined, its closure object lives in scratch memory)
         constexpr int ACT = decltype(act_tag)::value;
         const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
         const float* sc = xcoef + (long long)b * 2 * Cin + ch;
@@ -223,15 +233,24 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
     // fragment register sets carried across the nine unrolled taps - igemm3's schedule - needs > 256 VGPRs here: 160 spilled
     // registers, 557 instead of 810 TFLOP/s on the layer mix.)
+#ifdef RS_SPLIT_ABLATE
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 1] = clock64();
+#endif
 #pragma unroll
     for (int k = 0; k < XPW; ++k) issue_x(0, k);
-    issue_w(0);
+    issue_w(0, 0);
+    if (NSLOT == 3 && nst > 1) issue_w(1, 1);
     for (int c = 0; c < nch; ++c) {
         const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = c * 9 + tap;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight tile s (and every halo piece issued before it) has landed
+            // weight tile s (and every halo piece issued before it) has landed: with three slots only the loads of tile s+1 - the
+            // youngest RW (waves that also own a partial row group) or RWF ones of this wave - may still be in flight
+            if (NSLOT == 3 && s + 1 < nst) {
+                if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tap == 0) {
                 if (xcoef) {
@@ -255,8 +274,9 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             }
             // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
             if (c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
-            if (s + 1 < nst && (!(ABL & 1) || s < 1)) issue_w(s + 1);
-            const char* wb = smem + WBASE + (s & 1) * WSLOT + la;
+            // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
+            if (s + NSLOT - 1 < nst && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+            const char* wb = smem + WBASE + (NSLOT == 3 ? tap % 3 : (s & 1)) * WSLOT + la;
             const int ky = tap / 3, kx = tap % 3;
             if constexpr (SPLIT) {
                 f16x8 ah[FC], al[FC], bh[FP], bl[FP];
@@ -300,9 +320,12 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             }
         }
     }
-    __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
-
+#ifdef RS_SPLIT_ABLATE
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 2] = clock64();
+#endif
     // ---------------------------------------------------------------- epilogue
+    // (the barrier that ends the K loop comes after the residual loads below: their latency - the 4 x FC loads of a lane used to
+    // be issued per channel fragment, five round trips to L2 in a row, 8 - 10 k cycles of a 60 - 120 k cycle workgroup - overlaps it)
     // global pixel index of row r (0..63) of this wave's pixel tile
     auto pixel = [&](int r) -> long long {
         const int ty = TW == 64 ? wp : 2 * wp + (r >> 5);
@@ -351,6 +374,9 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
         const int act = p.act, ldres = p.ldres;
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+        // (split storage: the residual stays one channel fragment at a time - 16 registers; the prefetching variants of the fp16
+        // path push this kernel over 256 registers)
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             f16x4 rh[FP], rl[FP];
@@ -401,25 +427,31 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             __syncthreads();
         }
     } else {
-        auto finish = [&](auto act_tag) {
+        auto run = [&](auto res_tag) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(res_tag)::value;
+        f16x4 rv[FC][FP];   // the residual of the whole wave tile, all loads in flight together
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) rv[i][j] = *(const f16x4*)(res + mres[j] + nr);
+            }
+        }
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+        auto finish = [&](auto act_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-                f16x4 rv[FP];   // residual of this channel fragment (all FP loads in flight together)
-                if (res_ok) {
-                    const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) rv[j] = *(const f16x4*)(res + mres[j] + nr);
-                }
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
                     f32x4 v = acc[i][j] * p.out_scale + bvs[i];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
-                    if (res_ok) {
+                    if constexpr (RES) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[j][r];
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
                     }
                     f16x4 h;
                     h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
@@ -437,6 +469,8 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
         else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
         else finish(std::integral_constant<int, RS_ACT_NONE>{});
+        };
+        if (res_ok) run(std::true_type{}); else run(std::false_type{});
         if (ystats) stats_out();
         __syncthreads();
         for (int idx = lane; idx < NITEM; idx += 64) {
@@ -446,12 +480,32 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
     }
+#ifdef RS_SPLIT_ABLATE
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 3] = clock64();
+#endif
 }
+
+#ifdef RS_SPLIT_ABLATE
+}  // namespace
+// ablate builds: mean cycles of the three kernel phases over the first `nwg` workgroups of the last igemm4 launch
+extern "C" int rs_igemm4_phase_cycles(int nwg, double* out3) {
+    static long long h[4 * 8192];
+    if (nwg < 1 || nwg > 8192) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ig4_clk), sizeof(long long) * 4 * nwg) != hipSuccess) return -1;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    for (int i = 0; i < nwg; ++i)
+        for (int k = 0; k < 3; ++k) out3[k] += (double)(h[4 * i + k + 1] - h[4 * i + k]) / nwg;
+    return 0;
+}
+namespace {
+#endif
 
 template <int TW, int BC, bool SPLIT>
 hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     constexpr int TH = 256 / TW;
-    constexpr size_t lds = (size_t)2 * ((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128 + 2 * BC * 128;
+    constexpr size_t xbuf = (size_t)((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128;
+    constexpr size_t lds = 2 * xbuf + ((2 * xbuf + 3 * BC * 128 <= 160 * 1024) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
     const int tiles = p.B * (p.Ho / TH) * (p.Wo / TW) * ((p.Cout + BC - 1) / BC);
     static bool attr_set = false;
     if (!attr_set) {
@@ -500,12 +554,15 @@ extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int 
     if (!((in_dt == RS_F16 && (on & 1)) || (in_dt == RS_F16S && (on & 2)))) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
     if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && (p.ldres % 4))) return 0;
-    const int tw = (p.Wo % 64 == 0) ? 64 : 32, th = 256 / tw;
-    if ((p.Wo % tw) || (p.Ho % th)) return 0;
     auto waste = [&](int bc) { return ((p.Cout + bc - 1) / bc) * bc - p.Cout; };
     int best = 128, bw = waste(128);
     if (waste(160) < bw) { best = 160; bw = waste(160); }
     if (waste(192) < bw) { best = 192; bw = waste(192); }
+    // 4 x 64 tiles on planes that allow them, except for the 160-channel tile: 8 x 32 leaves room for the third weight slot
+    int tw = (p.Wo % 64 == 0) ? 64 : 32;
+    if (best == 160 && (p.Wo % 32 == 0) && (p.Ho % 8 == 0)) tw = 32;
+    const int th = 256 / tw;
+    if ((p.Wo % tw) || (p.Ho % th)) return 0;
     if (p.Cout < 96 || (in_dt == RS_F16S && best == 192)) return 0;   // (split, BC = 192: over the register budget; no 3x3 conv of the models needs it)
     const long long tiles = (long long)p.B * (p.Ho / th) * (p.Wo / tw) * ((p.Cout + best - 1) / best);
     if (tiles < min_tiles) return 0;

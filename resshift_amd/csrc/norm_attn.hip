@@ -742,6 +742,9 @@ __device__ __forceinline__ void lds_dma16_na(__amdgpu_buffer_rsrc_t r, char* lds
 // both, which is all S^T = K Q^T needs (the contraction index may be permuted consistently).  V goes through the same LDS
 // transposition as in win_attn_mfma_kernel, everything after that is identical.  The [M][3E] qkv tensor (151 MB at batch 32
 // on the 64x64 level) never exists.
+#ifdef RS_SPLIT_ABLATE
+__device__ int g_attn_abl = 0;   // timing ablation (RS_ATTN_ABL=1, ablate builds): every weight fragment comes from one cached line
+#endif
 __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsigned x_bytes) {
     constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
     constexpr int XS_STAGE = NT * 128;                       // 64 token rows x 128 B per 64-wide K stage
@@ -781,7 +784,12 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wf[f][ks] = *(const f16x8*)(wq + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
+            for (int ks = 0; ks < KS; ++ks) {
+#ifdef RS_SPLIT_ABLATE
+                if (g_attn_abl) { wf[f][ks] = *(const f16x8*)(wq + lg * 8); continue; }
+#endif
+                wf[f][ks] = *(const f16x8*)(wq + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
+            }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const f32x4 bv = *(const f32x4*)(p.bqkv + n0 + 16 * f + 4 * lg);
@@ -943,7 +951,12 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf2[f][ks] = *(const f16x8*)(wp + (long long)(h * HD + 16 * f + lr) * E + ks * 32 + lg * 8);
+        for (int ks = 0; ks < KS; ++ks) {
+#ifdef RS_SPLIT_ABLATE
+            if (g_attn_abl) { wf2[f][ks] = *(const f16x8*)(wp + lg * 8); continue; }
+#endif
+            wf2[f][ks] = *(const f16x8*)(wp + (long long)(h * HD + 16 * f + lr) * E + ks * 32 + lg * 8);
+        }
     f32x4 acc2[2][4];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -993,6 +1006,12 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 2;
     if (xb >= 0xF0000000ull) return -2;
     const size_t lds = 3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16);
+#ifdef RS_SPLIT_ABLATE
+    {
+        static const int abl = []() { const char* v = getenv("RS_ATTN_ABL"); const int a = v ? atoi(v) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &a, sizeof(int)); return a; }();
+        (void)abl;
+    }
+#endif
     hipLaunchKernelGGL(win_attn_qkv_kernel, dim3((p.H / 8) * (p.W / 8), p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

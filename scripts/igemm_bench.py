@@ -91,6 +91,11 @@ for name, Ho, Cin, Cout, k, stride, up, act, res, cnt in SHAPES:
     M, K = B * Ho * Ho, k * k * Cin
     fl = 2.0 * M * Cout * K
     print(f"{name:28s} {M:8d} {Cout:5d} {K:6d} {ms.value:8.3f} {fl / ms.value / 1e9:8.1f} {cnt:6d} {ms.value * cnt:8.2f}", flush=True)
+    if hasattr(lib, "rs_igemm4_phase_cycles") and os.environ.get("RS_IG4_PHASES"):   # ablate builds: in-kernel phase timing of the halo kernel
+        out3 = (C.c_double * 3)()
+        lib.rs_igemm4_phase_cycles.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        if lib.rs_igemm4_phase_cycles(256, out3) == 0:
+            print(f"    igemm4 phases (mean s_memtime ticks over 256 workgroups): setup {out3[0]:.0f}  K loop {out3[1]:.0f}  epilogue {out3[2]:.0f}", flush=True)
     tot_ms += ms.value * cnt
     tot_fl += fl * cnt
     del x, w, y, r
