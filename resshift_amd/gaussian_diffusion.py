@@ -97,7 +97,7 @@ class ResShiftDiffusion:
         return F16 if torch.is_autocast_enabled() else F32
 
     def set_precision(self, unet=None, encode=None, decode=None):
-        """unet: 'fp16' | 'fp32' | list with one entry per timestep t (index = t)."""
+        """unet: 'fp16' | 'fp32' | 'split' (alias 'fp16x3') | list with one entry per timestep t (index = t); encode / decode: one name."""
         self.precision_unet, self.precision_encode, self.precision_decode = unet, encode, decode
 
     def _unet_precisions(self):
