@@ -232,7 +232,7 @@ def main():
             else:
                 traffic_note = "profiles/ PMC file was collected on different kernel sources: not reported"
         roofline = {
-            "bound": "mfma", "kernel": "igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp_kernel / win_attn_qkv_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels)",
+            "bound": "mfma", "kernel": "igemm4_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / win_attn_qkv_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels)",
             "achieved": round(achieved, 2), "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
             "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_note": traffic_note,
             "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),

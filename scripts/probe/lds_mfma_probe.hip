@@ -8,9 +8,15 @@
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
 
 template <int MODE, int NRD, int NMM>   // MODE bit 0: reads, bit 1: MFMAs, bit 2: software-pipelined (reads of i+1 behind MFMAs of i)
-__global__ __launch_bounds__(512, 2) void probe(float* out, int iters, long long* clk) {
+// MODE bit 4: LDS-DMA refills (3 one-KB pieces per wave and iteration = 24 KB per CU, igemm4's weight tile + halo piece), waited
+// for in front of the barrier (bit 6: only the PREVIOUS iteration's pieces are waited for: one iteration of lead); bit 5: the same source lines for every CU (as the weight tile is) instead of distinct ones
+__global__ __launch_bounds__(512, 2) void probe(float* out, int iters, long long* clk, const f16* src) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     for (int i = tid; i < 36 * 1024; i += 512) ((float*)smem)[i] = (float)(i & 255) * 1e-3f;
@@ -22,9 +28,17 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int iters, long long
 #pragma unroll
     for (int r = 0; r < NRD; ++r) fr[r] = f16x8{1, 2, 3, 4, 5, 6, 7, 8};
     const int base = (wave * 16 + lr) * 128 + ((lg ^ (lr & 7)) << 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 64u << 20, 0x00020000);
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
         const int off = (it & 7) * 2048;
+        if (MODE & 16) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned piece = (unsigned)(it * 24 + wave * 3 + q) + ((MODE & 32) ? 0u : blockIdx.x * 4099u);
+                lds_dma16(rs, smem + 80 * 1024 + (wave * 3 + q) * 1024, (piece & 32767u) * 1024u + lane * 16u);
+            }
+        }
         if (MODE & 1) {
 #pragma unroll
             for (int r = 0; r < NRD; ++r) fr[r] = *(const f16x8*)(smem + base + ((off + r * 8192) & 0xFFFF));
@@ -37,6 +51,7 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int iters, long long
 #pragma unroll
             for (int r = 0; r < NRD; ++r) acc[r % 10][0] += (float)fr[r][0];
         }
+        if (MODE & 16) { if (MODE & 64) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (MODE & 8) __builtin_amdgcn_s_barrier();
     }
     const long long t1 = clock64();
@@ -52,10 +67,12 @@ void run(const char* name, float* out, long long* clk, int iters) {
     (void)hipFuncSetAttribute((const void*)probe<MODE, NRD, NMM>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<MODE, NRD, NMM>), dim3(256), dim3(512), 144 * 1024, 0, out, iters, clk);
+    static f16* src = nullptr;
+    if (!src) { (void)hipMalloc(&src, 64u << 20); (void)hipMemset(src, 0, 64u << 20); }
+    hipLaunchKernelGGL((probe<MODE, NRD, NMM>), dim3(256), dim3(512), 144 * 1024, 0, out, iters, clk, src);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((probe<MODE, NRD, NMM>), dim3(256), dim3(512), 144 * 1024, 0, out, iters, clk);
+    hipLaunchKernelGGL((probe<MODE, NRD, NMM>), dim3(256), dim3(512), 144 * 1024, 0, out, iters, clk, src);
     (void)hipEventRecord(e1, 0);
     (void)hipDeviceSynchronize();
     float ms = 0.f;
@@ -82,5 +99,12 @@ int main() {
     run<7, 9, 40>("9 reads behind 40 MFMAs", out, clk, it);
     run<7, 13, 80>("13 reads behind 80 MFMAs (128x80 wave tile)", out, clk, it);
     run<3, 9, 40>("9 reads, wait, 40 MFMAs", out, clk, it);
+    run<11 + 16, 18, 40>("reads, wait, MFMAs, barrier + LDS-DMA (distinct lines per CU)", out, clk, it);
+    run<11 + 48, 18, 40>("reads, wait, MFMAs, barrier + LDS-DMA (same lines for all CUs)", out, clk, it);
+    run<10 + 48, 18, 40>("MFMAs + barrier + LDS-DMA (same lines), no fragment reads", out, clk, it);
+    run<9 + 48, 18, 40>("reads + barrier + LDS-DMA (same lines), no MFMAs", out, clk, it);
+    run<11 + 48 + 64, 18, 40>("reads, wait, MFMAs, barrier + LDS-DMA with one iteration of lead", out, clk, it);
+    run<15 + 48 + 64, 18, 40>("reads behind MFMAs, barrier + LDS-DMA with one iteration of lead", out, clk, it);
+    run<10 + 48 + 64, 18, 40>("MFMAs + barrier + LDS-DMA with lead, no fragment reads", out, clk, it);
     return 0;
 }
