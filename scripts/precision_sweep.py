@@ -34,6 +34,13 @@ policies = {
     "unet-split": (["split"] * T, "fp16", "fp16"),
     "split-last8+enc": (["split" if t < 8 else "fp16" for t in range(T)], "split", "fp16"),
 }
+# split-last<k>+enc: split-precision encoder, the first T-k sampling steps (t = T-1 .. k) in fp16, the last k (t = k-1 .. 0) in split
+# precision, fp16 decoder.  An error made at step t reaches the final latent damped by the posterior coefficients
+# (x_{t-1} = eta_{t-1}/eta_t x_t + alpha_t/eta_t x0_pred, models/gaussian_diffusion.py:218-221; eta_0 = 0), so the early steps
+# tolerate fp16.
+for k in (1, 2, 3, 4, 5, 6, 10, 12):
+    policies[f"split-last{k}+enc"] = (["split" if t < k else "fp16" for t in range(T)], "split", "fp16")
+    policies[f"split-last{k}+enc16"] = (["split" if t < k else "fp16" for t in range(T)], "fp16", "fp16")
 if len(sys.argv) > 1:
     policies = {k: policies[k] for k in sys.argv[1:]}
 yb = y.repeat(32, 1, 1, 1).to(dev); nb = torch.stack(noises, 0).repeat(1, 32, 1, 1, 1).to(dev)
