@@ -329,30 +329,61 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
     }
     const f16* res = p.res ? (const f16*)p.res + 2 * z * p.bs_res : nullptr;   // residual: split storage, pixel stride ldres
     const bool quad = (p.Cout & 3) == 0 && (p.ldres & 3) == 0;
-    // scale, bias, activation, residual of one fragment, in place
-    auto finish = [&](int i, int j) {
+    // The epilogue is VALU / memory work that no MFMA overlaps (one workgroup per CU), so it is kept lean like igemm2's: the bias of
+    // every channel fragment is fetched once up front, the residual of channel fragment i+1 is in flight while fragment i is
+    // finished (one L2 round trip per channel fragment instead of one per 16 x 16 fragment: 24 in a row for a 128 x 192 tile
+    // were most of a short-K launch), and the activation is a compile-time choice behind one uniform branch.
+    const bool res_fast = res && quad;
+    f32x4 bvs[FC];
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
         const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
-        const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = am[i][j][r] * p.out_scale;
-            if (p.bias && n + r < p.Cout) t += p.bias[n + r];
-            v[r] = p.act == RS_ACT_GELU ? rs_gelu(t) : (p.act == RS_ACT_SILU ? rs_silu(t) : t);
+        bvs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            if ((p.Cout & 3) == 0) bvs[i] = *(const f32x4*)(p.bias + min(n, p.Cout - 4));
+            else for (int r = 0; r < 4; ++r) bvs[i][r] = n + r < p.Cout ? p.bias[n + r] : 0.f;
         }
-        if (res && m < p.M && n < p.Cout) {
-            const f16* rp = res + (long long)m * p.ldres * 2 + n;
-            if (quad && n + 3 < p.Cout) {
-                const f16x4 rh = *(const f16x4*)rp, rl = *(const f16x4*)(rp + p.ldres);
+    }
+    long long mres[FP];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[r], rl[r]);
-            } else {
-                for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += rs_join(rp[r], rp[p.ldres + r]);
-            }
-        }
+    for (int j = 0; j < FP; ++j) mres[j] = (long long)min(m0 + wp * (BP / WPN) + j * 16 + lr, p.M - 1) * p.ldres * 2;
+    f16x4 rh[2][FP], rl[2][FP];
+    auto load_res = [&](int i) __attribute__((always_inline)) {   // (clamped, branch-free: rows / channels outside the output are never stored)
+        const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) am[i][j][r] = v[r];
+        for (int j = 0; j < FP; ++j) { rh[i & 1][j] = *(const f16x4*)(res + mres[j] + nr); rl[i & 1][j] = *(const f16x4*)(res + mres[j] + p.ldres + nr); }
     };
+    // scale, bias, activation, residual of channel fragment row i, in place
+    auto finish_row = [&](int i, auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            f32x4 v = am[i][j] * p.out_scale + bvs[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ACT == RS_ACT_GELU ? rs_gelu(v[r]) : (ACT == RS_ACT_SILU ? rs_silu(v[r]) : v[r]);
+            if (res_fast) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[i & 1][j][r], rl[i & 1][j][r]);
+            } else if (res) {
+                const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
+                if (m < p.M)
+                    for (int r = 0; r < 4 && n + r < p.Cout; ++r) v[r] += rs_join(res[(long long)m * p.ldres * 2 + n + r], res[(long long)m * p.ldres * 2 + p.ldres + n + r]);
+            }
+            am[i][j] = v;
+        }
+    };
+    auto finish_all = [&](auto act_tag) __attribute__((always_inline)) {
+        if (res_fast) load_res(0);
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            if (res_fast && i + 1 < FC) load_res(i + 1);
+            finish_row(i, act_tag);
+        }
+    };
+    if (p.act == RS_ACT_GELU) finish_all(std::integral_constant<int, RS_ACT_GELU>{});
+    else if (p.act == RS_ACT_SILU) finish_all(std::integral_constant<int, RS_ACT_SILU>{});
+    else finish_all(std::integral_constant<int, RS_ACT_NONE>{});
     if constexpr (std::is_same<TO, h2s>::value) {
         f16* y = (f16*)p.y + 2 * z * p.bs_y;
         // wave tile (BP/WPN rows x BC/2 channels) staged twice (hi, lo) with a padded row pitch, then 16-byte stores
@@ -363,7 +394,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
         for (int i = 0; i < FC; ++i)
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
-                finish(i, j);
                 f16x4 h, l;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f16 a, b; rs_split(am[i][j][r], a, b); h[r] = a; l[r] = b; }
@@ -402,7 +432,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             for (int i = 0; i < FC; ++i) {
                 const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
                 if (m >= p.M || n >= p.Cout) continue;
-                finish(i, j);
                 float* yp = y + (long long)m * p.ldy + n;
                 if (n + 3 < p.Cout && vec_ok) *(f32x4*)yp = am[i][j];
                 else for (int r = 0; r < 4 && n + r < p.Cout; ++r) yp[r] = am[i][j][r];
