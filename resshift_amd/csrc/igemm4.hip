@@ -375,23 +375,24 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
         const int act = p.act, ldres = p.ldres;
         __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
-        // (split storage: the residual stays one channel fragment at a time - 16 registers; the prefetching variants of the fp16
-        // path push this kernel over 256 registers)
+        // (split storage: all FC fragment rows at once would need 80 registers next to the 80 accumulators)
+        f16x4 rh[2][FP], rl[2][FP];   // residual of channel fragment i + 1 in flight while fragment i is finished
+        auto load_res = [&](int i) __attribute__((always_inline)) {
+            const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { rh[i & 1][j] = *(const f16x4*)(res + mres[j] + nr); rl[i & 1][j] = *(const f16x4*)(res + mres[j] + ldres + nr); }
+        };
+        if (res_ok) load_res(0);
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
-            f16x4 rh[FP], rl[FP];
-            if (res_ok) {
-                const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
-#pragma unroll
-                for (int j = 0; j < FP; ++j) { rh[j] = *(const f16x4*)(res + mres[j] + nr); rl[j] = *(const f16x4*)(res + mres[j] + ldres + nr); }
-            }
+            if (res_ok && i + 1 < FC) load_res(i + 1);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 f32x4 v = acc[i][j] * osc + bvs[i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (act == RS_ACT_SILU) v[r] = rs_silu(v[r]); else if (act == RS_ACT_GELU) v[r] = rs_gelu(v[r]);
-                    if (res_ok) v[r] += rs_join(rh[j][r], rl[j][r]);
+                    if (res_ok) v[r] += rs_join(rh[i & 1][j][r], rl[i & 1][j][r]);
                 }
                 acc[i][j] = v;
             }

@@ -394,6 +394,21 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
     // ---- epilogue: 2^-11 O + b2 + residual, then the hi and the lo halves through LDS into 16-byte stores
     constexpr int ROWB = (E / 2) * 2 + 16;
     char* stg = smem + wave * 32 * ROWB;
+    // (the residual of the whole wave tile in flight at once - 48 registers, the token fragments are dead by now: loaded per
+    // fragment it was twelve L2 round trips in a row)
+    const bool res_ok = p.res != nullptr;
+    f16x4 rh[FC2][2], rl[FC2][2];
+    if (res_ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres * 2;
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) {
+                const int n = wc * (E / 2) + i * 16 + lg * 4;
+                rh[i][j] = *(const f16x4*)(p.res + mr + n); rl[i][j] = *(const f16x4*)(p.res + mr + p.ldres + n);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FC2; ++i) {
         const int n = wc * (E / 2) + i * 16 + lg * 4;
@@ -401,11 +416,9 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f32x4 v = o[i][j] * RS_LO_INV + bv;
-            if (p.res) {
-                const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres * 2;
-                const f16x4 rh = *(const f16x4*)(p.res + mr + n), rl = *(const f16x4*)(p.res + mr + p.ldres + n);
+            if (res_ok) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[r], rl[r]);
+                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[i][j][r], rl[i][j][r]);
             }
             o[i][j] = v;
         }
