@@ -34,8 +34,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // ABL (builds with -DRS_SPLIT_ABLATE only): timing ablations of the K loop, results wrong: 1 = no refill loads after the
 // prologue, 2 = no ds_read / MFMA, 4 = no barrier (compile-time: runtime switches in the loop cost registers)
+#ifdef RS_SPLIT_ABLATE
+__device__ long long g_igs_clk[4 * 8192];   // per workgroup: cycle counter at kernel start / K loop start / K loop end / kernel end (ablate builds)
+#define RS_IGS_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0) g_igs_clk[4 * blockIdx.x + (k)] = clock64()
+#else
+#define RS_IGS_STAMP(k)
+#endif
 template <typename TO, int BP, int BC, int NWV, bool PIPE, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel(IGemmParams p) {
+    RS_IGS_STAMP(0);
     constexpr int WPN = NWV / 2;               // pixel-waves (x 2 channel-waves)
     constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
     constexpr int BK = 64;                     // halfs of K per stage (128 bytes of hi + 128 bytes of lo per row)
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
 #pragma unroll
         for (int j = 0; j < FP; ++j) { am[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    RS_IGS_STAMP(1);
     if (nk > 0) issue(0);
     if (nk > 1) issue(1);
     if constexpr (!PIPE) {
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             stage(nk - 1, std::false_type{}, std::true_type{});
         }
     }
+    RS_IGS_STAMP(2);
     __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
 
     // ---------------------------------------------------------------- epilogue
@@ -325,6 +334,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
                 else for (int r = 0; r < 4 && n + r < p.Cout; ++r) pp[r] = am[i][j][r];
             }
         }
+        RS_IGS_STAMP(3);
         return;
     }
     const f16* res = p.res ? (const f16*)p.res + 2 * z * p.bs_res : nullptr;   // residual: split storage, pixel stride ldres
@@ -347,11 +357,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
     long long mres[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) mres[j] = (long long)min(m0 + wp * (BP / WPN) + j * 16 + lr, p.M - 1) * p.ldres * 2;
-    f16x4 rh[2][FP], rl[2][FP];
+    // (the whole wave tile's residual at once - 48 registers - was measured too: no further gain, the remaining epilogue time of
+    // the short-K launches is the latency of the first residual / bias round trip itself and the two staging passes)
+    constexpr int RSLOT = 2;
+    f16x4 rh[RSLOT][FP], rl[RSLOT][FP];
     auto load_res = [&](int i) __attribute__((always_inline)) {   // (clamped, branch-free: rows / channels outside the output are never stored)
         const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
 #pragma unroll
-        for (int j = 0; j < FP; ++j) { rh[i & 1][j] = *(const f16x4*)(res + mres[j] + nr); rl[i & 1][j] = *(const f16x4*)(res + mres[j] + p.ldres + nr); }
+        for (int j = 0; j < FP; ++j) { rh[i % RSLOT][j] = *(const f16x4*)(res + mres[j] + nr); rl[i % RSLOT][j] = *(const f16x4*)(res + mres[j] + p.ldres + nr); }
     };
     // scale, bias, activation, residual of channel fragment row i, in place
     auto finish_row = [&](int i, auto act_tag) __attribute__((always_inline)) {
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             for (int r = 0; r < 4; ++r) v[r] = ACT == RS_ACT_GELU ? rs_gelu(v[r]) : (ACT == RS_ACT_SILU ? rs_silu(v[r]) : v[r]);
             if (res_fast) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[i & 1][j][r], rl[i & 1][j][r]);
+                for (int r = 0; r < 4; ++r) v[r] += rs_join(rh[i % RSLOT][j][r], rl[i % RSLOT][j][r]);
             } else if (res) {
                 const int m = m0 + wp * (BP / WPN) + j * 16 + lr;
                 if (m < p.M)
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             }
         }
     }
+    RS_IGS_STAMP(3);
 }
 
 template <typename TO, int BP, int BC, int NWV, bool PIPE, int ABL = 0>
@@ -526,6 +540,20 @@ extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC) {
 }
 
 // in: split storage; out_dt: RS_F16S or RS_F32.  Single source only (C1 == 0), C0 / ld0 / Ktot multiples of 8.
+#ifdef RS_SPLIT_ABLATE
+// ablate builds: mean cycles of the three kernel phases over the first `nwg` workgroups of the last igemm_split launch
+extern "C" int rs_igemm_split_phase_cycles(int nwg, double* out3) {
+    static long long h[4 * 8192];
+    if (nwg < 1 || nwg > 8192) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_igs_clk), sizeof(long long) * 4 * nwg) != hipSuccess) return -1;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    for (int i = 0; i < nwg; ++i)
+        for (int k = 0; k < 3; ++k) out3[k] += (double)(h[4 * i + k + 1] - h[4 * i + k]) / nwg;
+    return 0;
+}
+#endif
+
 extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st) {
     const IGemmParams& p = *pp;
     if (p.C1 != 0 || (p.C0 % 8) || (p.ld0 % 8) || (p.Ktot % 8)) return -2;
