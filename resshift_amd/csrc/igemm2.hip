@@ -86,10 +86,17 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef RS_SPLIT_ABLATE
+__device__ long long g_ig2_clk[4 * 8192];   // per workgroup: cycle counter at kernel start / K loop start / K loop end / kernel end (ablate builds)
+#define RS_IG2_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0) g_ig2_clk[4 * blockIdx.x + (k)] = clock64()
+#else
+#define RS_IG2_STAMP(k)
+#endif
 template <typename TI, typename TO, int BP, int BC, int NS, int NWV>
 // second launch bound = waves per SIMD the register allocation must allow: the 2-stage 128-pixel variant lives on TWO
 // co-resident workgroups per CU (4 waves per SIMD, <= 128 VGPRs); one spilled-over register halves its occupancy
 __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NWV == 16) ? 4 : 2) void igemm2_kernel(IGemmParams p) {
+    RS_IG2_STAMP(0);
     constexpr int WPN = NWV / 2;               // pixel-waves (x 2 channel-waves)
     constexpr int RND = 8 * NWV;               // rows covered by one LDS-DMA instruction of every wave
     constexpr int CH = MfmaOps<TI>::CH;
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
 
     // prologue: fill NS-1 ring slots - and, with only two slots, the second one as well: both are empty at this point, so
     // stages 0 and 1 travel together and every workgroup saves one full load round trip (short-K launches have only 3)
+    RS_IG2_STAMP(1);
     if (nk > 0) issue(0);
     const bool pro2 = NS >= 3 || !(p.dbg & 64);   // (dbg 64: the 2-slot ring starts with one stage, for A/B timing)
     if (nk > 1 && pro2) issue(1);
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
         const char* sb = smem + (kt % NS) * STAGE;
         if (!(p.dbg & 2)) Stage2<TI, FC, FP>::run(sb + la + swz0, sb + la + swz1, sb + lb + swz0, sb + lb + swz1, acc);
     }
+    RS_IG2_STAMP(2);
     __syncthreads();  // all waves done with the ring: the epilogue reuses it as staging space
 
     // ---------------------------------------------------------------- epilogue (as in igemm.hip)
@@ -271,6 +280,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
                 else for (int r = 0; r < 4 && n + r < p.Cout; ++r) pp[r] = acc[i][j][r];
             }
         }
+        RS_IG2_STAMP(3);
         return;
     }
     TO* y = (TO*)p.y + z * p.bs_y;
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
             }
         }
     }
+    RS_IG2_STAMP(3);
 }
 
 template <typename TI, typename TO, int BP, int BC, int NS, int NWV = 8>
@@ -484,6 +495,20 @@ hipError_t launch2_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t s
 
 // Tile choice of the second-generation kernel; returns 0 when the launch should stay on igemm.hip (tiny Cout,
 // too few tiles to fill the chip -> split-K there).
+#ifdef RS_SPLIT_ABLATE
+// ablate builds: mean cycles of the three kernel phases over the first `nwg` workgroups of the last igemm2 launch
+extern "C" int rs_igemm2_phase_cycles(int nwg, double* out3) {
+    static long long h[4 * 8192];
+    if (nwg < 1 || nwg > 8192) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ig2_clk), sizeof(long long) * 4 * nwg) != hipSuccess) return -1;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    for (int i = 0; i < nwg; ++i)
+        for (int k = 0; k < 3; ++k) out3[k] += (double)(h[4 * i + k + 1] - h[4 * i + k]) / nwg;
+    return 0;
+}
+#endif
+
 extern "C" int rs_igemm2_pick(int M, int Cout, int Kbytes, int nz, int* BP, int* BC) {
     if (Cout <= 64) return 0;
     auto waste = [&](int bc) { return ((Cout + bc - 1) / bc) * bc - Cout; };

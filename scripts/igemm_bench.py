@@ -96,6 +96,11 @@ for name, Ho, Cin, Cout, k, stride, up, act, res, cnt in SHAPES:
         lib.rs_igemm4_phase_cycles.argtypes = [C.c_int, C.POINTER(C.c_double)]
         if lib.rs_igemm4_phase_cycles(256, out3) == 0:
             print(f"    igemm4 phases (mean s_memtime ticks over 256 workgroups): setup {out3[0]:.0f}  K loop {out3[1]:.0f}  epilogue {out3[2]:.0f}", flush=True)
+    if hasattr(lib, "rs_igemm2_phase_cycles") and os.environ.get("RS_IG2_PHASES"):   # ablate builds: phases of igemm2
+        out3 = (C.c_double * 3)()
+        lib.rs_igemm2_phase_cycles.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        if lib.rs_igemm2_phase_cycles(64, out3) == 0:
+            print(f"    igemm2 phases (mean s_memtime ticks over 64 workgroups): setup {out3[0]:.0f}  K loop {out3[1]:.0f}  epilogue {out3[2]:.0f}", flush=True)
     if hasattr(lib, "rs_igemm_split_phase_cycles") and os.environ.get("RS_IGS_PHASES"):   # ablate builds: phases of the split implicit GEMM
         out3 = (C.c_double * 3)()
         lib.rs_igemm_split_phase_cycles.argtypes = [C.c_int, C.POINTER(C.c_double)]
