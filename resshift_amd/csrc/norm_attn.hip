@@ -745,54 +745,63 @@ __device__ __forceinline__ void lds_dma16_na(__amdgpu_buffer_rsrc_t r, char* lds
 #ifdef RS_SPLIT_ABLATE
 __device__ int g_attn_abl = 0;   // timing ablation (RS_ATTN_ABL=1, ablate builds): every weight fragment comes from one cached line
 #endif
+// NW windows per workgroup (1 or 2): a wave's q / k / v / proj weight fragments are fetched from L2 once and applied to the tokens
+// of NW windows.  The kernel is bound by that weight stream (295 KB per window, 2.4 GB per launch on the 64 x 64 level at batch
+// 32 - with every fragment read from one cached line instead it is 29 % faster, profiles/r2_swin_mlp_split_ablation.txt), so two
+// windows per workgroup halve its dominant traffic; the attention itself runs window after window on the same registers.
+template <int NW>
 __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsigned x_bytes) {
     constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
     constexpr int XS_STAGE = NT * 128;                       // 64 token rows x 128 B per 64-wide K stage
+    constexpr int XS_WIN = 3 * XS_STAGE;                     // token tile of one window
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    f16* vt = (f16*)(smem + 3 * XS_STAGE) + (size_t)h * HD * VP;   // [HD][VP] of this head
     const int nwx = p.W / WS;
-    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
     const int b = blockIdx.y;
-    auto pixel = [&](int t) -> long long {
+    auto vt_of = [&](int w) { return (f16*)(smem + NW * XS_WIN) + (size_t)(w * 6 + h) * HD * VP; };   // [HD][VP] of (window, head)
+    auto win_y = [&](int w) { return (int)(blockIdx.x * NW + w) / nwx; };
+    auto pixel = [&](int w, int t) -> long long {
+        const int wi = blockIdx.x * NW + w;
+        const int wy = wi / nwx, wx = wi - wy * nwx;
         int sy = wy * WS + (t >> 3) + p.shift; if (sy >= p.H) sy -= p.H;
         int sx = wx * WS + (t & 7) + p.shift; if (sx >= p.W) sx -= p.W;
         return ((long long)b * p.H + sy) * p.W + sx;
     };
-    // ---- tokens of the window -> LDS: 8 row groups x 3 K stages = 24 LDS-DMA instructions, 4 per wave
+    // ---- tokens of the windows -> LDS: per window 8 row groups x 3 K stages = 24 LDS-DMA instructions, 4 per wave
     {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
         const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int it = h * 4 + q, st = it >> 3, grp = it & 7;
-            const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldx + st * 64 + kcp * 8) * 2u;
-            lds_dma16_na(rx, smem + st * XS_STAGE + (grp * 8) * 128, off);
-        }
-    }
-    long long pix[4];
+        for (int w = 0; w < NW; ++w)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) pix[f] = pixel(16 * f + lr);
+            for (int q = 0; q < 4; ++q) {
+                const int it = h * 4 + q, st = it >> 3, grp = it & 7;
+                const unsigned off = (unsigned)(pixel(w, grp * 8 + rsub) * p.ldx + st * 64 + kcp * 8) * 2u;
+                lds_dma16_na(rx, smem + w * XS_WIN + st * XS_STAGE + (grp * 8) * 128, off);
+            }
+    }
     const f16* wq = (const f16*)p.wqkv;
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
-    // one projection pass: this head's 32 output features starting at weight row n0 -> acc[2 feature frags][4 token frags]
-    auto project = [&](int n0, f32x4 (&acc)[2][4]) {
-        f16x8 wf[2][KS];
+    // this head's 32 output features starting at weight row n0: fragments straight from L2 in MFMA A-operand layout
+    auto load_w = [&](const f16* wsrc, int n0, f16x8 (&wf)[2][KS]) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #ifdef RS_SPLIT_ABLATE
-                if (g_attn_abl) { wf[f][ks] = *(const f16x8*)(wq + lg * 8); continue; }
+                if (g_attn_abl) { wf[f][ks] = *(const f16x8*)(wsrc + lg * 8); continue; }
 #endif
-                wf[f][ks] = *(const f16x8*)(wq + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
+                wf[f][ks] = *(const f16x8*)(wsrc + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
             }
+    };
+    // one projection pass over the token tile of window w -> acc[2 feature frags][4 token frags] (bias in the accumulator)
+    auto project = [&](int w, const f16x8 (&wf)[2][KS], const float* bias, int n0, f32x4 (&acc)[2][4]) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const f32x4 bv = *(const f32x4*)(p.bqkv + n0 + 16 * f + 4 * lg);
+            const f32x4 bv = *(const f32x4*)(bias + n0 + 16 * f + 4 * lg);
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) acc[f][fi] = bv;
         }
@@ -800,7 +809,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         for (int ks = 0; ks < KS; ++ks) {
             f16x8 xb[4];
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi) xb[fi] = *(const f16x8*)(smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1]);
+            for (int fi = 0; fi < 4; ++fi) xb[fi] = *(const f16x8*)(smem + w * XS_WIN + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1]);
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -815,113 +824,129 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // the window's tokens are in LDS
+    __syncthreads();   // the windows' tokens are in LDS
     if (p.xcoef) {
         // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c], rounded to fp16 exactly where the separate apply kernel
-        // rounds.  64 rows x 24 chunks of 8 channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
+        // rounds.  Per window 64 rows x 24 chunks of 8 channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
         const float* sc = p.xcoef + (long long)b * 2 * E;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int item = tid + 384 * q;              // 0 .. 1535
-            const int st = item >> 9, t = (item >> 3) & 63, ps = item & 7;
-            const int c0 = st * 64 + ((ps ^ (t & 7)) << 3);
-            f16x8* cell = (f16x8*)(smem + st * XS_STAGE + t * 128 + ps * 16);
-            f16x8 v = *cell;
-            const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
-            const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+        for (int w = 0; w < NW; ++w)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = (f16)fmaf((float)v[e], a0[e], d0[e]); v[4 + e] = (f16)fmaf((float)v[4 + e], a1[e], d1[e]); }
-            *cell = v;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const int item = tid + 384 * q;              // 0 .. 1535
+                const int st = item >> 9, t = (item >> 3) & 63, ps = item & 7;
+                const int c0 = st * 64 + ((ps ^ (t & 7)) << 3);
+                f16x8* cell = (f16x8*)(smem + w * XS_WIN + st * XS_STAGE + t * 128 + ps * 16);
+                f16x8 v = *cell;
+                const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
+                const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = (f16)fmaf((float)v[e], a0[e], d0[e]); v[4 + e] = (f16)fmaf((float)v[4 + e], a1[e], d1[e]); }
+                *cell = v;
+            }
         __syncthreads();
     }
-    f16x8 kf[4], qf[4];
+    f16x8 kf[NW][4], qf[NW][4];
     {
+        f16x8 wf[2][KS];
         f32x4 acc[2][4];
-        project(h * HD, acc);            // q_h: lane (lr,lg) holds d = {4lg+r, 16+4lg+r} of token 16fi+lr
-        pack(acc, qf);
-        project(E + h * HD, acc);        // k_h: the same d set per lane -> a consistent contraction order for S^T
-        pack(acc, kf);
-        project(2 * E + h * HD, acc);    // v_h -> V^T[d][token] in LDS
+        // (scheduling fences between the passes: two windows' passes interleaved by the compiler do not fit 256 registers)
+        load_w(wq, h * HD, wf);            // q_h: lane (lr,lg) holds d = {4lg+r, 16+4lg+r} of token 16fi+lr
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int w = 0; w < NW; ++w) { project(w, wf, p.bqkv, h * HD, acc); pack(acc, qf[w]); __builtin_amdgcn_sched_barrier(0); }
+        load_w(wq, E + h * HD, wf);        // k_h: the same d set per lane -> a consistent contraction order for S^T
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
+        for (int w = 0; w < NW; ++w) { project(w, wf, p.bqkv, E + h * HD, acc); pack(acc, kf[w]); __builtin_amdgcn_sched_barrier(0); }
+        load_w(wq, 2 * E + h * HD, wf);    // v_h -> V^T[d][token] in LDS
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vt[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = (f16)acc[f][ft][r];
-    }
-    f32x4 s[4][4];  // [fj][fi]
+        for (int w = 0; w < NW; ++w) {
+            __builtin_amdgcn_sched_barrier(0);
+            project(w, wf, p.bqkv, 2 * E + h * HD, acc);
+            f16* vt = vt_of(w);
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj)
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
-            s[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[fj], qf[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
-    if (p.shift > 0) {
-        auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
-        rid_i = band(lr & 7);
+                for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
-    }
-    float inv[4];
-    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi) {
-        const int i = 16 * fi + lr;
-        float m = -3.0e38f;
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
-                if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
-                s[fj][fi][r] = v;
-                m = fmaxf(m, v);
-            }
+                    for (int r = 0; r < 4; ++r) vt[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = (f16)acc[f][ft][r];
         }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f;
+    }
+    __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tiles (they are overwritten below)
+    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+    f16* out = (f16*)p.out;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        __builtin_amdgcn_sched_barrier(0);   // window after window: interleaving two windows' score tiles would need > 256 registers
+        f32x4 s[4][4];  // [fj][fi]
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[fj][fi][r] - m);
-                s[fj][fi][r] = e;
-                l += e;
-            }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        inv[fi] = 1.0f / l;
-    }
-    __syncthreads();  // V^T of every head is in LDS (only this head's is read, but the barrier also orders the ds_writes)
-    f32x4 o[2][4];    // [fd][fi]
+            for (int fi = 0; fi < 4; ++fi)
+                s[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[w][fj], qf[w][fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+        if (p.shift > 0) {
+            const int wy = win_y(w);
+            auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
+            rid_i = band(lr & 7);
 #pragma unroll
-    for (int fd = 0; fd < 2; ++fd)
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        f16x8 va[2], pb[4];
-#pragma unroll
-        for (int fd = 0; fd < 2; ++fd) {
-            const f16* row = vt + (16 * fd + lr) * VP + 32 * ks + 4 * lg;
-            const f16x4 lo = *(const f16x4*)row, hi = *(const f16x4*)(row + 16);
-            va[fd] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
         }
+        float inv[4];
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
-            const f32x4 a = s[2 * ks][fi], c = s[2 * ks + 1][fi];
-            pb[fi] = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+            const int i = 16 * fi + lr;
+            float m = -3.0e38f;
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj) {
+                const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                    if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
+                    s[fj][fi][r] = v;
+                    m = fmaxf(m, v);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[fj][fi][r] - m);
+                    s[fj][fi][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            inv[fi] = 1.0f / l;
         }
+        f32x4 o[2][4];    // [fd][fi]
 #pragma unroll
         for (int fd = 0; fd < 2; ++fd)
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
-    }
-    f16* out = (f16*)p.out;
-    if (!p.wproj) {
+            for (int fi = 0; fi < 4; ++fi) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f16* vt = vt_of(w);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 va[2], pb[4];
+#pragma unroll
+            for (int fd = 0; fd < 2; ++fd) {
+                const f16* row = vt + (16 * fd + lr) * VP + 32 * ks + 4 * lg;
+                const f16x4 lo = *(const f16x4*)row, hi = *(const f16x4*)(row + 16);
+                va[fd] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const f32x4 a = s[2 * ks][fi], c = s[2 * ks + 1][fi];
+                pb[fi] = f16x8{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3], (f16)c[0], (f16)c[1], (f16)c[2], (f16)c[3]};
+            }
+#pragma unroll
+            for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
+        }
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -929,69 +954,44 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                 f16x4 hv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
-                *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * fd + 4 * lg) = hv;
+                const int t = 16 * fi + lr, c = h * HD + 16 * fd + 4 * lg;     // token row, feature
+                if (!p.wproj) *(f16x4*)(out + pixel(w, t) * p.ldo + c) = hv;
+                // fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format)
+                else *(f16x4*)(smem + w * XS_WIN + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2) = hv;
             }
-        return;
     }
-    // ---- fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format), then
-    // wave h produces output features 32h .. 32h+31 for all 64 tokens: 48 MFMAs, weights straight from L2 like the qkv passes
-    __syncthreads();   // every wave is done with the token tile (projection passes) before it is overwritten
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-        for (int fd = 0; fd < 2; ++fd) {
-            f16x4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
-            const int t = 16 * fi + lr, c = h * HD + 16 * fd + 4 * lg;     // token row, feature
-            *(f16x4*)(smem + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2) = hv;
-        }
-    const f16* wp = (const f16*)p.wproj;
+    if (!p.wproj) return;
+    // ---- fused output projection: wave h produces output features 32h .. 32h+31 for all tokens: 48 MFMAs per window, weights
+    // straight from L2 like the qkv passes
     f16x8 wf2[2][KS];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#ifdef RS_SPLIT_ABLATE
-            if (g_attn_abl) { wf2[f][ks] = *(const f16x8*)(wp + lg * 8); continue; }
-#endif
-            wf2[f][ks] = *(const f16x8*)(wp + (long long)(h * HD + 16 * f + lr) * E + ks * 32 + lg * 8);
-        }
-    f32x4 acc2[2][4];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const f32x4 bv = *(const f32x4*)(p.bproj + h * HD + 16 * f + 4 * lg);
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) acc2[f][fi] = bv;
-    }
-    f16x4 rv[2][4];
+    load_w((const f16*)p.wproj, h * HD, wf2);
     const f16* res = (const f16*)p.res;
-    if (res) {
+    __syncthreads();   // all heads' attention results are in LDS
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        __builtin_amdgcn_sched_barrier(0);
+        long long pix[4];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) pix[fi] = pixel(w, 16 * fi + lr);
+        f16x4 rv[2][4];
+        if (res) {
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) rv[f][fi] = *(const f16x4*)(res + pix[fi] * p.ldres + h * HD + 16 * f + 4 * lg);
+        }
+        f32x4 acc2[2][4];
+        project(w, wf2, p.bproj, h * HD, acc2);
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) rv[f][fi] = *(const f16x4*)(res + pix[fi] * p.ldres + h * HD + 16 * f + 4 * lg);
+            for (int f = 0; f < 2; ++f) {
+                f16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
+                *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * f + 4 * lg) = hv;
+            }
     }
-    __syncthreads();   // all heads' attention results are in LDS
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        f16x8 xb[4];
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) xb[fi] = *(const f16x8*)(smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1]);
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi) acc2[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf2[f][ks], xb[fi], acc2[f][fi], 0, 0, 0);
-    }
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            f16x4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
-            *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * f + 4 * lg) = hv;
-        }
 }
 
 }  // namespace
@@ -1005,14 +1005,24 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     if (p.wproj && (!p.bproj || (p.res && (p.ldres % 4)))) return -2;
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 2;
     if (xb >= 0xF0000000ull) return -2;
-    const size_t lds = 3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16);
+    // two windows per workgroup wherever an image has an even number of them (RS_ATTN_NW=1: one, for A/B runs)
+    static const int nw_max = []() { const char* v = getenv("RS_ATTN_NW"); return v ? atoi(v) : 2; }();
+    const int nwin = (p.H / 8) * (p.W / 8);
+    const int NW = (nw_max >= 2 && nwin % 2 == 0) ? 2 : 1;
+    const size_t lds = (size_t)NW * (3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16));
 #ifdef RS_SPLIT_ABLATE
     {
         static const int abl = []() { const char* v = getenv("RS_ATTN_ABL"); const int a = v ? atoi(v) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &a, sizeof(int)); return a; }();
         (void)abl;
     }
 #endif
-    hipLaunchKernelGGL(win_attn_qkv_kernel, dim3((p.H / 8) * (p.W / 8), p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    if (NW == 2) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    } else {
+        hipLaunchKernelGGL(win_attn_qkv_kernel<1>, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
