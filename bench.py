@@ -9,8 +9,13 @@ pass of the whole hot path over one batch: bicubic x4 -> VQ-f4 encode -> prior s
 update) -> VQ lookup -> VQ-f4 decode, i.e. one `rs_sample` call of the engine.  `--config` selects the other BASELINE
 configurations (journal: 4 steps; faceir: 512x512, f8 autoencoder, batch 16; inpaint: 256x256 + mask, batch 16).
 
-For N > 1 the driver launches one process per GPU (torchrun); rank 0 packs the weights and the blob reaches the other
-ranks through ONE RCCL broadcast; every rank then processes its own batch (weak scaling, no data-path collective).
+N > 1: one process per GPU (sampler.py:66-77).  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: WORLD_SIZE / RANK are in the environment) or `python bench.py --gpus N` launches
+them itself: it re-executes this file under torch.distributed.run with a free rendezvous port on 127.0.0.1.  Backend RCCL
+("nccl") when N GPUs are visible; fewer GPUs than ranks is refused unless RESSHIFT_DIST_BACKEND=gloo asks for the
+ranks-share-a-GPU plumbing configuration.  Rank 0 packs the weights and the blob reaches the other ranks through ONE
+broadcast; every rank then processes its own batch (weak scaling, no data-path collective).  The line carries `n_gpus` =
+the world size of the process group, the per-rank images/sec, and the broadcast's bytes and time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   * `roofline`      MFMA implicit-GEMM kernel family (hipEvent timed on the launch stream in a dedicated pass) and, under
@@ -126,9 +131,23 @@ def main():
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: become one (one process per GPU, sampler.py:66-77).  The children see WORLD_SIZE and skip this.
+        import subprocess
+
+        try:
+            backend = sharding.pick_backend(args.gpus)
+        except RuntimeError as ex:
+            raise SystemExit(f"[bench] refused: {ex}")
+        cmd = sharding.launch_command(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        print(f"[bench] launching {args.gpus} ranks ({backend}): {' '.join(cmd)}", file=sys.stderr, flush=True)
+        env = dict(os.environ, RESSHIFT_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("NCCL_DEBUG", "VERSION")   # one line with the RCCL version on stderr when the communicator comes up
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     world, rank = sharding.init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.set_grad_enabled(False)
 
@@ -196,6 +215,7 @@ def main():
     sharding.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = sharding.allgather_floats([elapsed, float(torch.cuda.current_device())], dev)
     elapsed = sharding.allreduce_max(elapsed, dev)
     assert torch.isfinite(out).all().item(), "non-finite output"
     ms_per_step = elapsed / args.steps * 1e3
@@ -294,8 +314,8 @@ def main():
 
         parity = [engine_parity(args.precision, headline)]
         cpu_baseline = {"value": round(nb / cpu_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                        "what": "oracle/ (functional restatement of the reference on torch CPU ops; about 20 % FASTER than the reference "
-                                "modules' own loop at B=1, oracle/make_golden.py, so GPU/CPU ratios are understated)",
+                        "what": "oracle/ (functional restatement of the reference on torch CPU ops; 20-35 % FASTER than the reference "
+                                "modules' own loop at B=1 (box-dependent, oracle/make_golden.py), so GPU/CPU ratios are understated)",
                         "sample": f"{nb} images, same weights/inputs/noise as the first {nb} images of the GPU batch, full {steps}-step loop, fp32",
                         "seconds": round(cpu_s, 2), "gpu_vs_cpu_psnr_db": parity[0]["image_psnr_db"]}
         log(f"cpu baseline {cpu_baseline['value']} img/s; headline parity {parity[0]}")
@@ -303,8 +323,10 @@ def main():
         if args.precision != PARITY_POLICY:
             pol = policy_args(PARITY_POLICY, steps)
             par = engine_parity(PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", pol)
-            ms = timed(pol, 3)
-            par.update({"ms_per_step": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 2), "steps_timed": 3})
+            for _ in range(max(0, args.warmup - 1)):   # timed like the headline: same warm-up and step counts
+                run(pol)
+            ms = timed(pol, args.steps)
+            par.update({"ms_per_step": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 2), "steps_timed": args.steps, "warmup": args.warmup})
             if not args.no_profile_pass:
                 eng.profile_enable(True)
                 run(pol)
@@ -373,6 +395,12 @@ def main():
             "config": {"workload": f"{cname}: batch {B}/GPU x {world} GPU, {cdesc}, random-init weights",
                        "precision_policy": args.precision, "kernel_launches_per_step": launches, "weight_setup_s": round(setup_s, 2),
                        "parallelism": f"dp{world} (batch sharded, one RCCL weight broadcast, no data-path collective)"},
+            "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                      "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "gpus_visible": torch.cuda.device_count(),
+                      "per_rank": [{"rank": r, "device": int(v[1]), "images_per_sec": round(B * args.steps / v[0], 3)} for r, v in enumerate(per_rank)],
+                      "weight_broadcast_bytes": int(getattr(eng, "broadcast_bytes", 0)),
+                      "weight_broadcast_ms": round(1e3 * float(getattr(eng, "broadcast_s", 0.0)), 3)},
             "value_at_parity": value_at_parity,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "torch_rocm_autocast_baseline": torch_baseline,

@@ -157,7 +157,9 @@ def current_stream_ptr() -> int:
 
 def window_copy(x, h0=0, w0=0, ho=None, wo=None, scale=1.0, out=None):
     """fp32 device tensor [..., H, W] -> [..., ho, wo] window starting at (h0, w0), reflected past the bottom / right edge and
-    multiplied by `scale` (rs_window_copy: reflect padding, tile crops and the latent scaling of the host mirror)."""
+    multiplied by `scale` (rs_window_copy: reflect padding, tile crops and the latent scaling of the host mirror).  The result is
+    always float32 (the engine's user-facing tensors are fp32 like the reference's inference path; F.pad / slicing in the
+    reference keep the input dtype, which is float32 there too)."""
     import torch
 
     if not x.is_cuda:
@@ -167,7 +169,11 @@ def window_copy(x, h0=0, w0=0, ho=None, wo=None, scale=1.0, out=None):
     ho = H if ho is None else ho
     wo = W if wo is None else wo
     planes = x.numel() // (H * W)
+    want = (*x.shape[:-2], ho, wo)
     if out is None:
-        out = torch.empty(*x.shape[:-2], ho, wo, device=x.device, dtype=torch.float32)
+        out = torch.empty(*want, device=x.device, dtype=torch.float32)
+    elif out.dtype != torch.float32 or tuple(out.shape) != want or not out.is_contiguous() or out.device != x.device:
+        raise ValueError(f"window_copy: `out` must be a contiguous float32 tensor of shape {want} on {x.device} "
+                         f"(got {out.dtype}, {tuple(out.shape)}, contiguous={out.is_contiguous()}, {out.device})")
     check(load().rs_window_copy(x.data_ptr(), out.data_ptr(), planes, H, W, h0, w0, ho, wo, float(scale), current_stream_ptr()), "rs_window_copy")
     return out

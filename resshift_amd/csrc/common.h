@@ -51,6 +51,11 @@ template <> __device__ __forceinline__ float rs_ld<h2s>(const h2s* p, int lo) { 
 template <typename T> __device__ __forceinline__ void rs_st(T* p, int lo, float v) { *p = (T)v; }
 template <> __device__ __forceinline__ void rs_st<h2s>(h2s* p, int lo, float v) { f16 h, l; rs_split(v, h, l); ((f16*)p)[0] = h; ((f16*)p)[lo] = l; }
 
+// per-device "function attribute already set" flags of the launchers (hipFuncSetAttribute is per device: a process that drives
+// several GPUs must set the dynamic-LDS limit on each of them)
+#define RS_MAX_DEVICES 64
+static inline int rs_device_slot() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < RS_MAX_DEVICES ? d : 0; }
+
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float rs_silu(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (nn.GELU() default; reference models/swin_transformer.py:18)

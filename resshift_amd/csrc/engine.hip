@@ -121,7 +121,9 @@ struct Arena {
 
 struct Exec {
     hipStream_t st = nullptr; Arena* arena = nullptr; bool dry = false; long long launches = 0; int err = 0;
+    bool used_split = false;   // a split-storage tensor was allocated: the call needs the split weights (checked after the dry run)
     View T(int B, int H, int W, int C, int dt) {
+        if (dt == RS_F16S) used_split = true;
         View v; v.B = B; v.H = H; v.W = W; v.C = C; v.ld = C; v.dt = dt;
         v.p = arena->alloc((size_t)B * H * W * C * rs_dtype_size(dt));
         return v;
@@ -259,6 +261,12 @@ struct rs_engine {
     size_t blob_bytes = 0;
     bool bound = false, ready = false;
     std::string build_err;
+    // Split precision is optional per checkpoint: the halo kernel scales the hi weight fragment by 2^11 in fp16, which is exact only
+    // for |w| < 32 (igemm4.hip).  A checkpoint with a larger (or non-finite) conv / linear weight still loads and runs in fp16 /
+    // fp32; only a call that asks for RS_PREC_SPLIT fails.  The verdict travels IN the blob (first word of a 256-byte header), so
+    // ranks that receive the blob by broadcast know it too.
+    std::string split_err;
+    bool split_ok = true;
     Arena arena;
     long long last_launches = 0;
     Exec::Prof prof, prof_gn;
@@ -346,7 +354,7 @@ struct rs_engine {
                                 f16 h, l;
                                 const float wv = w[((size_t)co * Cin + ci) * KH * KW + t];
                                 // (the halo kernel scales the hi fragment by 2^11 in fp16: exact below 32)
-                                if (!(std::fabs(wv) < 30.0f) && build_err.empty()) build_err = "split precision needs |weight| < 30: " + wkey;
+                                if (!(std::fabs(wv) < 30.0f) && split_err.empty()) split_err = "split precision needs |weight| < 30: " + wkey;
                                 rs_split(wv, h, l);
                                 const size_t k = (size_t)t * CinP + ci;
                                 o[(size_t)co * 2 * K + k] = h;
@@ -588,7 +596,9 @@ struct rs_engine {
     size_t build(char* base, bool fill) {
         blob.base = base; blob.off = 0; blob.fill = fill;
         build_err.clear();
+        split_err.clear();
         if (fill) blob.staging.assign(blob_bytes, 0);
+        (void)blob.add(256, [](char*) {});   // header: word 0 = flags (bit 0: split weights usable), written by rs_pack_weights
         if (cfg.has_unet) build_unet();
         if (cfg.has_ae) build_ae();
         return (blob.off + 255) & ~(size_t)255;
@@ -1160,6 +1170,10 @@ struct rs_engine {
         Exec d; d.st = st; d.arena = &arena; d.dry = true; d.keep = debug;
         arena.off = 0; arena.peak = 0;
         fn(d);
+        if (d.used_split && !(cfg.enable_split && split_ok))
+            return fail(!cfg.enable_split ? "split precision requested but the engine was created without enable_split"
+                                          : "split precision is not available for these weights: " +
+                                                (split_err.empty() ? std::string("a conv / linear weight with |w| >= 30 or a non-finite value (the packing rank has its name)") : split_err));
         const size_t need = arena.peak + 4096;
         if (need > arena.cap) {
             (void)hipStreamSynchronize(st);
@@ -1289,6 +1303,11 @@ int rs_pack_weights(rs_engine* e) {
     e->build(base, true);
     e->collect_film_blocks();
     if (!e->build_err.empty()) { e->blob.staging.clear(); e->blob.staging.shrink_to_fit(); return fail(e->build_err); }
+    e->split_ok = e->split_err.empty();
+    {
+        const uint32_t flags = e->split_ok ? 1u : 0u;
+        memcpy(e->blob.staging.data(), &flags, sizeof flags);
+    }
     if (hipMemcpy(base, e->blob.staging.data(), e->blob_bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy of weight blob failed");
     e->blob.staging.clear(); e->blob.staging.shrink_to_fit();
     e->blob.fill = false;
@@ -1301,6 +1320,9 @@ int rs_pack_weights(rs_engine* e) {
 
 int rs_weights_ready(rs_engine* e) {
     if (!e || !e->bound) return fail("rs_weights_ready: bind a weight blob first");
+    uint32_t flags = 0;   // header word of the blob (packed here, read from a cache file, or received by broadcast)
+    if (hipMemcpy(&flags, e->blob.base, sizeof flags, hipMemcpyDeviceToHost) != hipSuccess) return fail("rs_weights_ready: cannot read the blob header");
+    e->split_ok = (flags & 1u) != 0;
     for (auto& kv : e->film_cache) (void)hipFree(kv.second);
     e->film_cache.clear();
     e->ready = true;

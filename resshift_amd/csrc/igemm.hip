@@ -334,7 +334,8 @@ hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     dim3 grid(tiles, 1, p.splitk > 1 ? p.splitk : nz);
     const size_t lds = 2 * (BP + BC) * 128;
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<TI, TO, BP, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;

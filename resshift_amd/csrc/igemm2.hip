@@ -411,7 +411,8 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)NS * (BP + BCP) * 128;
     static_assert(NS * (BP + BCP) * 128 <= 160 * 1024, "LDS");
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm2_kernel<TI, TO, BP, BC, NS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;

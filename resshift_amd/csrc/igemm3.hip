@@ -321,7 +321,8 @@ template <typename TO, int BC>
 hipError_t launch3_cfg(IGemmParams p, hipStream_t st) {
     const int tiles = ((p.M + 255) / 256) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)3 * (256 + BC) * 128;
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm3_kernel<TO, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;

@@ -508,7 +508,8 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     constexpr size_t xbuf = (size_t)((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128;
     constexpr size_t lds = 2 * xbuf + ((2 * xbuf + 3 * BC * 128 <= 160 * 1024) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
     const int tiles = p.B * (p.Ho / TH) * (p.Wo / TW) * ((p.Cout + BC - 1) / BC);
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;

@@ -459,7 +459,8 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     constexpr size_t lds = (size_t)2 * 2 * (BP + BC) * 128;
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_split_kernel<TO, BP, BC, NWV, PIPE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;

@@ -1017,7 +1017,8 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     }
 #endif
     if (NW == 2) {
-        static bool attr_set = false;
+        static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
         hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
     } else {
@@ -1043,7 +1044,8 @@ extern "C" int rs_win_attn_launch(const WinAttnParams* pp, int dt, hipStream_t s
     } else if (dt == RS_F16S) {
         static const bool valu = []() { const char* e = getenv("RS_ATTN_SPLIT_VALU"); return e && e[0] == '1'; }();   // A/B knob: fp32 VALU kernel
         if (p.bias_n && !valu) {
-            const size_t lds_m = (size_t)p.heads * 2 * 32 * (64 + 8) * sizeof(f16);
+            const size_t lds_m = (size_t)p.heads * 2 * 32 * (64 + 8) * sizeof(f16);   // 72 KB at 8 heads: over the 64 KB default
+            (void)hipFuncSetAttribute((const void*)win_attn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(win_attn_split_kernel, grid, block, lds_m, st, p);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }

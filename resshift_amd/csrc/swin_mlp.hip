@@ -228,7 +228,8 @@ extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
     p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
     constexpr int LDS = 160 * 1024;
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)swin_mlp_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
@@ -457,7 +458,8 @@ extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const flo
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
     p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
     constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
-    static bool attr_set = false;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)swin_mlp_split_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;

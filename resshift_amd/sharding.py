@@ -18,6 +18,40 @@ import torch.distributed as dist
 from . import _lib
 
 
+def free_port() -> int:
+    """A TCP port that is free on 127.0.0.1 right now (taken from a bound socket, so two launches on one node do not collide
+    on a fixed rendezvous port)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def pick_backend(world: int) -> str:
+    """RCCL ("nccl" on ROCm) when every rank has its own GPU.  Several ranks on one GPU is a plumbing-test configuration only:
+    it has to be asked for with RESSHIFT_DIST_BACKEND=gloo, otherwise the launch is refused (RCCL cannot put two ranks on one
+    device, and a silent fallback would report a one-GPU number as a multi-GPU one)."""
+    forced = os.environ.get("RESSHIFT_DIST_BACKEND")
+    if forced:
+        return forced
+    if not torch.cuda.is_available():
+        return "gloo"
+    if torch.cuda.device_count() < world:
+        raise RuntimeError(f"{world} ranks requested but only {torch.cuda.device_count()} GPU(s) are visible: one process per GPU over "
+                           f"RCCL needs {world} devices (set RESSHIFT_DIST_BACKEND=gloo to let the ranks share a GPU for a plumbing test)")
+    return "nccl"
+
+
+def launch_command(script: str, script_args: Sequence[str], nproc: int) -> list:
+    """`python -m torch.distributed.run` command line that runs `script` as `nproc` ranks of one node (one process per GPU,
+    sampler.py:66-77), rendezvous on 127.0.0.1 at a free port."""
+    import sys
+
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), script, *script_args]
+
+
 def init_distributed() -> Tuple[int, int]:
     """Returns (world_size, rank).  Initialises the process group from the torchrun environment when WORLD_SIZE > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -28,10 +62,20 @@ def init_distributed() -> Tuple[int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # RCCL ("nccl") on GPUs; RESSHIFT_DIST_BACKEND=gloo lets several ranks share one GPU for plumbing tests
-        backend = os.environ.get("RESSHIFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL ("nccl") with one GPU per rank; RESSHIFT_DIST_BACKEND=gloo lets several ranks share one GPU for plumbing tests
+        backend = pick_backend(world)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return world, rank
+
+
+def allgather_floats(values: Sequence[float], device) -> list:
+    """[world][len(values)] python floats: every rank's `values` (bench: per-rank times)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [list(values)]
+    t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [[float(v) for v in p.cpu()] for p in parts]
 
 
 def barrier() -> None:
@@ -98,7 +142,7 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return _lib.window_copy(x, 0, 0, H + pad_h, W + pad_w)
 
 
-BLOB_CACHE_MAGIC = b"RSBLOB03"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+BLOB_CACHE_MAGIC = b"RSBLOB04"   # bump when the packed layout (csrc/engine.hip weight builder) changes
 
 
 def checkpoint_fingerprint(paths) -> bytes:
@@ -173,10 +217,16 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
         if blob_cache:
             torch.cuda.synchronize(dev)
             _blob_cache_save(blob_cache, eng, cache_fingerprint)
+    eng.broadcast_s, eng.broadcast_bytes = 0.0, 0
     if world > 1:
+        import time
+
         torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
         broadcast_blob(eng.weight_blob(), src=0)
         torch.cuda.synchronize(dev)
+        eng.broadcast_s, eng.broadcast_bytes = time.perf_counter() - t0, int(eng.weight_blob().numel())
     eng.mark_weights_ready()
     # the module shells hand out THIS engine from now on (model(x, t), encode / decode, the step-wise sampling API): on ranks
     # other than 0, and on rank 0 after a blob-cache hit, their own parameters were never filled - an engine rebuilt from

@@ -39,7 +39,10 @@ class TileSplitter:
         self.starts: List[Tuple[int, int]] = [(i, j) for i in extract_starts(height, pch_size, stride)
                                               for j in extract_starts(width, pch_size, stride)]
         self.count_pchs = 0
-        self.im_ori = im
+        # the crops read the image through rs_window_copy (device, contiguous fp32): convert ONCE, not per tile
+        if not im.is_cuda:
+            raise RuntimeError("TileSplitter needs a device tensor: the host mirror does not fall back to CPU arithmetic")
+        self.im_ori = im.detach().to(torch.float32).contiguous()
         self.out_shape = None  # allocated on the first update (the output channel count is the sampler's business)
         self.im_res = None
         self.pixel_count = None

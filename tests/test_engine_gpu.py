@@ -203,6 +203,135 @@ def test_other_baseline_configs_full_size_vs_oracle(gpu, cname, hw, with_mask):
     lat = H.psnr(g16["z_final"].cpu(), zr, peak_to_peak=(zr.max() - zr.min()).item())
     print(f"{cname} fp16: latent PSNR {lat:.1f} dB, image PSNR {H.psnr(out16.cpu().clamp(-1, 1), ref.clamp(-1, 1)):.1f} dB")
     assert lat >= 60.0   # measured 68.4 - 69.3 dB
+    # the parity-qualified policy the credited throughput is quoted on (bench.py PARITY_POLICY): split-precision encoder + UNet,
+    # fp16 decoder - north_star's criterion on every BASELINE configuration
+    T = dp["steps"]
+    d.set_precision(["split"] * T, "split", "fp16")
+    outp, gp = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                               step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    agree_p = (gp["indices"].cpu().long() == aux["indices"]).float().mean().item()
+    pp = H.psnr(outp.cpu().clamp(-1, 1), ref.clamp(-1, 1))
+    print(f"{cname} parity policy: image PSNR {pp:.1f} dB, VQ agreement {agree_p:.5f}")
+    assert pp >= 60.0 and agree_p >= 0.999
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The resolution-generic path: networks run at a latent size other than the one they were constructed for,
+# as every tile of the tiled mode whose latent is not image_size does (sampler.py:186-208).  The SW-MSA mask is rebuilt from the
+# runtime size while shift_size / window_size stay what the constructed resolution made them (models/swin_transformer.py:189-194,
+# 214-262).  Fixtures: tests/golden/reference_offsize.npz = outputs of the UNMODIFIED reference modules (oracle/make_golden_offsize.py).
+def _offsize_golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_offsize.npz"))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
+@pytest.mark.parametrize("tag", ["tiny@48x32", "tiny@32x16", "tiny_fe@32x48"])
+def test_unet_forward_offsize_vs_oracle(gpu, tag, prec):
+    from oracle import make_golden_offsize as mo
+
+    up, ap, dp, with_mask, B, hz, wz = mo.TINY_CASES[tag]
+    usd, asd = H.weights(up, ap)
+    um, _ = _shells(up, ap, usd, asd, gpu)
+    y, noises, mask = mo.case_inputs(tag)
+    x, t = noises[1] * 1.3, torch.tensor([2] * B)
+    kw = {"lq": y}
+    if with_mask:
+        kw["mask"] = mask
+    ref = oc.unet_forward(usd, up, x, t, **kw)
+    got = um(x.to(gpu), t.to(gpu), prec=prec, **{k: v.to(gpu) for k, v in kw.items()})
+    torch.cuda.synchronize()
+    err, err_ref = H.rel_err(got, ref), H.rel_err(got, torch.from_numpy(_offsize_golden()[f"{tag}/unet"]))
+    print(f"unet {tag} {prec}: rel err {err:.3e} vs oracle, {err_ref:.3e} vs the reference's output")
+    assert err < TOL_NET[prec] and err_ref < TOL_NET[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "split"])
+@pytest.mark.parametrize("tag", ["tiny@48x32", "tiny@32x16", "tiny_fe@32x48"])
+def test_sample_loop_offsize_vs_oracle(gpu, tag, prec):
+    from oracle import make_golden_offsize as mo
+    from resshift_amd import create_gaussian_diffusion
+
+    up, ap, dp, with_mask, B, hz, wz = mo.TINY_CASES[tag]
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    y, noises, mask = mo.case_inputs(tag)
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    d = create_gaussian_diffusion(**dp)
+    d.set_precision(prec, prec, prec)
+    kw = {"lq": y.to(gpu)}
+    if with_mask:
+        kw["mask"] = mask.to(gpu)
+    out, gaux = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                                step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    zerr = H.rel_err(gaux["z_final"], aux["z_final"])
+    agree = (gaux["indices"].cpu().long() == aux["indices"]).float().mean().item()
+    p = H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1))
+    pg = H.psnr(out.cpu().clamp(-1, 1), torch.from_numpy(_offsize_golden()[f"{tag}/sample"]).clamp(-1, 1))
+    print(f"sample {tag} {prec}: latent rel err {zerr:.3e}, VQ agreement {agree:.4f}, image PSNR {p:.1f} dB ({pg:.1f} dB vs the reference's output)")
+    assert zerr < (2e-2 if prec == "fp16" else 5e-5)
+    if prec != "fp16":
+        assert agree >= 0.99 and p >= 60.0 and pg >= 60.0
+
+
+@pytest.mark.parametrize("policy", ["parity", "fp32"])
+def test_realsr_one_128_tile_vs_reference_output(gpu, policy):
+    """The headline network (constructed for 64 x 64 latents) on ONE 128 x 128 LR tile, B = 1, 15 steps: latent 128 x 128 (4 x 4 ..
+    16 x 16 windows per level, the 8 x 8 level of the construction becomes 2 x 2 unshifted windows), autoencoder attention over
+    T = 16 384 tokens, 512 x 512 output - against the UNMODIFIED reference modules' output for the same weights / input / noise."""
+    from oracle import make_golden_offsize as mo
+    from resshift_amd import create_gaussian_diffusion
+
+    g = _offsize_golden()
+    up, ap, dp = H.realsr_params()
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    y, noises, _ = mo.realsr_inputs(dp["steps"])
+    T = dp["steps"]
+    d = create_gaussian_diffusion(**dp)
+    if policy == "fp32":   # one exact UNet call against the reference's own
+        got = um((noises[1] * 1.3).to(gpu), torch.tensor([7]).to(gpu), lq=y.to(gpu), prec="fp32")
+        assert H.rel_err(got, torch.from_numpy(g["realsr128/unet"])) < TOL_NET["fp32"]
+    d.set_precision(*{"parity": (["split"] * T, "split", "fp16"), "fp32": ("fp32", "fp32", "fp32")}[policy])
+    out, aux = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False,
+                               model_kwargs={"lq": y.to(gpu)}, step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1, 3, 512, 512)
+    zerr = H.rel_err(aux["z_final"], torch.from_numpy(g["realsr128/sample_z"]))
+    agree = (aux["indices"].cpu().long() == torch.from_numpy(g["realsr128/sample_idx"].astype(np.int64))).float().mean().item()
+    p = H.psnr(out.cpu().clamp(-1, 1), torch.from_numpy(g["realsr128/sample"].astype(np.float32)).clamp(-1, 1))
+    print(f"realsr @ 128x128 {policy}: latent rel err {zerr:.2e}, VQ agreement {agree:.5f}, image PSNR {p:.1f} dB")
+    assert p >= 60.0 and agree >= 0.999
+
+
+@pytest.mark.parametrize("policy", ["fp32", "parity"])
+def test_tiled_path_tiles_larger_than_image_size(gpu, policy):
+    """sampler.py:186-208 with tiles whose latent (32 x 32) is NOT the constructed resolution (16 x 16): 56 x 40 LR input, 32-pixel
+    tiles with stride 24, against the oracle's tiled restatement and the reference's own ImageSpliterTh + modules output."""
+    from oracle import make_golden_offsize as mo
+    from resshift_amd import ResShiftSampler
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    T = mo.TILED
+    s = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, chop_size=T["chop_size"], chop_stride=T["chop_stride"], chop_bs=T["chop_bs"],
+                        padding_offset=T["padding_offset"], seed=1, state_dicts={"model": usd, "autoencoder": asd})
+    if policy == "parity":
+        s.base_diffusion.set_precision(["split"] * dp["steps"], "split", "fp16")
+    else:
+        s.base_diffusion.set_precision("fp32", "fp32", "fp32")
+    y, calls = mo.tiled_inputs(dp["steps"])
+    ref = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=T["chop_size"], chop_stride=T["chop_stride"], chop_bs=T["chop_bs"],
+                          padding_offset=T["padding_offset"])
+    out = s.sample_tiled(y.to(gpu), tile_noises=[(c[0].to(gpu), [n.to(gpu) for n in c[1:]]) for c in calls])
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1, 3, 224, 160) == tuple(ref.shape)
+    p, pg = H.psnr(out.cpu(), ref), H.psnr(out.cpu(), torch.from_numpy(_offsize_golden()["tiled32/sample"]))
+    print(f"tiled path, 32-pixel tiles of a 16-pixel network, {policy}: PSNR {p:.1f} dB vs oracle, {pg:.1f} dB vs the reference output")
+    assert p >= 60.0 and pg >= 60.0
 
 
 def test_tiled_large_image_path(gpu):
@@ -421,6 +550,54 @@ def test_batch32_parity_of_the_bench_policies(gpu, inputs):
         assert p_img >= min_img and p_lat >= min_lat and agree >= min_agree, (name, p_img, p_lat, agree)
 
 
+def test_fp16_error_on_natural_images_is_conditioning_not_a_kernel(gpu):
+    """the fp16 policy's latent PSNR is ~20 dB lower on the natural Val_SR images than on synthetic inputs.
+    Per network call nothing differs: with IDENTICAL call inputs, the fp16 kernels stay inside the same relative-error band against
+    the engine's own exact-fp32 kernels on both input sets (encoder, and UNet calls along the fp32 trajectory at three timesteps).
+    What differs is the network: on the smooth natural inputs the random-init sampler trajectory amplifies a perturbation of the
+    same relative size more over the 15 steps (measured here as the growth of an injected 1e-3 relative perturbation of z_y
+    through the exact fp32 loop) - conditioning, not a kernel."""
+    from resshift_amd import create_gaussian_diffusion
+
+    up, ap, dp, usd, asd, um, am = _realsr_models(gpu)
+    B, T = 8, dp["steps"]
+    errs, growth = {}, {}
+    for name in ("synthetic", "real_pixels"):
+        y, noises, _ = H.synth.synthetic_inputs(77, B, 64, 64, 3, 64, 64, T)
+        if name == "real_pixels":
+            y = _real_lq(B)
+        yg = y.to(gpu)
+        up4 = torch.nn.functional.interpolate(yg, scale_factor=4, mode="bicubic")
+        z32, z16 = am.encode(up4, prec="fp32"), am.encode(up4, prec="fp16")
+        e = [H.rel_err(z16, z32)]
+        x = z32 + 1.98 * noises[0].to(gpu)
+        for t in (14, 7, 0):
+            xt = x * (0.3 + 0.05 * t)
+            o32 = um(xt, torch.full((B,), t, device=gpu), lq=yg, prec="fp32")
+            o16 = um(xt, torch.full((B,), t, device=gpu), lq=yg, prec="fp16")
+            e.append(H.rel_err(o16, o32))
+        errs[name] = e
+        # sensitivity of the exact loop to a fixed relative perturbation of the latent fed to the loop
+        d = create_gaussian_diffusion(**dp)
+        d.set_precision("fp32", "fp32", "fp32")
+        base = d.p_sample_loop(yg, um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs={"lq": yg},
+                               step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)[1]["z_final"]
+        g = torch.Generator().manual_seed(5)
+        pert = (noises[0] + 1e-3 * torch.randn(noises[0].shape, generator=g)).to(gpu)
+        moved = d.p_sample_loop(yg, um, first_stage_model=am, noise=pert, clip_denoised=False, model_kwargs={"lq": yg},
+                                step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)[1]["z_final"]
+        growth[name] = H.rel_err(moved, base) / 1e-3
+    torch.cuda.synchronize()
+    print(f"fp16 vs own fp32 per call [encode, unet t=14, 7, 0]: synthetic {['%.2e' % v for v in errs['synthetic']]}, "
+          f"real pixels {['%.2e' % v for v in errs['real_pixels']]}; growth of a 1e-3 perturbation through the loop: "
+          f"synthetic x{growth['synthetic']:.2f}, real pixels x{growth['real_pixels']:.2f}")
+    for name in errs:
+        assert max(errs[name]) < TOL_NET["fp16"], (name, errs[name])
+    # same band on both input sets (within 3x of each other call by call): no input-dependent kernel defect
+    for a, b in zip(errs["synthetic"], errs["real_pixels"]):
+        assert b < 3.0 * a + 1e-4 and a < 3.0 * b + 1e-4, (errs,)
+
+
 def test_decoder_with_the_reference_indices_forced(gpu):
     """What separates the fp16 policy from the reference is ONLY the VQ argmin (ldm/modules/vqvae/quantize.py:276-285): with the
     oracle's code indices forced (codebook rows fed through decode(force_not_quantize=True)) the fp16 decoder reproduces the
@@ -476,7 +653,7 @@ def test_two_ranks_share_one_gpu(gpu, tmp_path, policy):
     out = tmp_path / "two_rank.pt"
     env = dict(os.environ, RESSHIFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(here, "_two_rank_worker.py"), str(out), policy]
+           "--master-port", str(__import__("resshift_amd.sharding", fromlist=["free_port"]).free_port()), os.path.join(here, "_two_rank_worker.py"), str(out), policy]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = torch.load(out)
@@ -494,6 +671,35 @@ def test_two_ranks_share_one_gpu(gpu, tmp_path, policy):
     assert torch.equal(got["out"], ref.cpu()), (got["out"] - ref.cpu()).abs().max().item()
     z = am.encode(torch.nn.functional.interpolate(y.to(gpu), scale_factor=4, mode="nearest"), prec="fp32")
     assert abs(got["zsum"] - float(z.abs().sum())) <= 1e-3 * float(z.abs().sum()) and got["zsum"] > 0   # rank 1's shells used real weights
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus N` - the command the driver runs - must start N ranks by itself (one process per GPU,
+    sampler.py:66-77).  On this one-GPU box the two ranks share the device (RESSHIFT_DIST_BACKEND=gloo); without that variable the
+    launch is refused loudly instead of silently timing one process."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESSHIFT_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "2", "--warmup", "1", "--no-profile-pass"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and len(line["ranks"]["per_rank"]) == 2
+    assert line["ranks"]["weight_broadcast_bytes"] > 100e6 and line["value"] > 0
+    per = sum(p["images_per_sec"] for p in line["ranks"]["per_rank"])
+    assert 0.5 * per <= line["value"] <= 1.05 * per      # whole-job value = all ranks' images over the max-over-ranks time
+    if torch.cuda.device_count() < 2:
+        env.pop("RESSHIFT_DIST_BACKEND")
+        r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r2.returncode != 0 and "refused" in (r2.stderr + r2.stdout)
 
 
 def test_tiled_path_one_side_shorter_than_the_tile(gpu):

@@ -326,3 +326,34 @@ def test_host_mirror_data_movement_needs_the_device():
 
     with pytest.raises(RuntimeError, match="device tensor"):
         sharding.reflect_pad(torch.zeros(1, 3, 8, 8), 2, 2)
+
+
+def test_bench_launcher_pieces(monkeypatch):
+    """`python bench.py --gpus N` starts its own ranks: the torch.distributed.run command line, the free rendezvous
+    port, and the backend rule - RCCL only with one GPU per rank, ranks sharing a GPU only when RESSHIFT_DIST_BACKEND=gloo asks
+    for it, otherwise a loud refusal (never a silent one-process run reported as N GPUs)."""
+    from resshift_amd import sharding
+
+    cmd = sharding.launch_command("/x/bench.py", ["--gpus", "4", "--steps", "3"], 4)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "3"]
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert 1024 < port < 65536 and port != 29500
+    monkeypatch.delenv("RESSHIFT_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert sharding.pick_backend(8) == "nccl" and sharding.pick_backend(2) == "nccl"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match="only 1 GPU"):
+        sharding.pick_backend(2)
+    monkeypatch.setenv("RESSHIFT_DIST_BACKEND", "gloo")
+    assert sharding.pick_backend(2) == "gloo"
+    # bench.py refuses instead of timing one process when it cannot give every rank a GPU
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RESSHIFT_DIST_BACKEND")}
+    src = ("import sys, torch; torch.cuda.is_available = lambda: True; torch.cuda.device_count = lambda: 1; "
+           "sys.argv = ['bench.py', '--gpus', '2']; import runpy; runpy.run_path(%r, run_name='__main__')" % os.path.join(H.ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refused" in r.stderr

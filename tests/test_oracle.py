@@ -73,6 +73,61 @@ def test_oracle_full_size_realsr_matches_reference_output():
     assert H.psnr(out.clamp(-1, 1), torch.from_numpy(g["realsr/sample"].astype(np.float32)).clamp(-1, 1)) > 60.0
 
 
+@pytest.mark.parametrize("tag", ["tiny@48x32", "tiny@32x16", "tiny_fe@32x48"])
+def test_oracle_offsize_matches_reference_outputs(tag):
+    """The resolution-generic path: the networks run at a latent size other than the constructed one -
+    per-size SW-MSA masks with the construction-time shift (models/swin_transformer.py:189-194,214-262), non-square maps.
+    tests/golden/reference_offsize.npz holds the unmodified reference modules' outputs (oracle/make_golden_offsize.py)."""
+    from oracle import make_golden_offsize as mo
+
+    g = np.load(mo.os.path.join(mo.GOLD, "reference_offsize.npz"))
+    up, ap, dp, with_mask, B, hz, wz = mo.TINY_CASES[tag]
+    usd, asd = H.weights(up, ap)
+    y, noises, mask = mo.case_inputs(tag)
+    kw = {"lq": y}
+    if with_mask:
+        kw["mask"] = mask
+    assert H.rel_err(oc.unet_forward(usd, up, noises[1] * 1.3, torch.tensor([2] * B), **kw), torch.from_numpy(g[f"{tag}/unet"])) < 2e-5
+    out, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    assert H.rel_err(aux["z_final"], torch.from_numpy(g[f"{tag}/sample_z"])) < 5e-5
+    assert (aux["indices"].numpy() == g[f"{tag}/sample_idx"]).mean() >= 0.995
+    assert H.psnr(out.clamp(-1, 1), torch.from_numpy(g[f"{tag}/sample"]).clamp(-1, 1)) > 70.0
+
+
+def test_oracle_offsize_full_network_and_tiles():
+    """The headline network (constructed for 64 x 64 latents) on a 128 x 128 latent: one UNet forward against the reference's
+    output (the 15-step loop at this size is pinned when the fixture is generated: 57 s of reference time); and the tiled path
+    with 32-pixel tiles of the tiny network (tile latent 32 x 32, constructed 16 x 16) against the reference's ImageSpliterTh."""
+    from oracle import make_golden_offsize as mo
+
+    g = np.load(mo.os.path.join(mo.GOLD, "reference_offsize.npz"))
+    up, ap, dp = H.realsr_params()
+    usd, _ = H.weights(up, ap)
+    y, noises, _ = mo.realsr_inputs(dp["steps"])
+    assert H.rel_err(oc.unet_forward(usd, up, noises[1] * 1.3, torch.tensor([7]), lq=y), torch.from_numpy(g["realsr128/unet"])) < 2e-5
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    y, calls = mo.tiled_inputs(dp["steps"])
+    T = mo.TILED
+    got = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=T["chop_size"], chop_stride=T["chop_stride"], chop_bs=T["chop_bs"],
+                          padding_offset=T["padding_offset"])
+    assert (got - torch.from_numpy(g["tiled32/sample"])).abs().max().item() <= 2e-5
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_oracle_offsize_live_against_reference_modules():
+    """live: the reference UNet at 48 x 32 and 32 x 16 on a network constructed for 16 x 16 (bit-exact)"""
+    U, _, _ = ref_import.load()
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, _ = H.weights(up, ap)
+    um = U(**up).eval()
+    um.load_state_dict(usd, strict=True)
+    g = torch.Generator().manual_seed(11)
+    for (h, w) in ((48, 32), (32, 16), (16, 48)):
+        x, y = torch.randn(2, 3, h, w, generator=g), torch.rand(2, 3, h, w, generator=g) * 2 - 1
+        assert torch.equal(oc.unet_forward(usd, up, x, torch.tensor([1, 1]), lq=y), um(x, torch.tensor([1, 1]), lq=y))
+
+
 @pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
 def test_oracle_live_against_reference_modules():
     U, V, create = ref_import.load()
