@@ -186,10 +186,12 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
                        int out_prec, int reps, float* ms_out, void* stream);
 /* halo-tile 3x3 conv with the GroupNorm affine + activation of its input fused in (igemm4.hip): y = conv3x3(act_in(x * coef[b][0][c]
  * + coef[b][1][c])) (+res); x / res / y NHWC device tensors in `prec` storage (RS_PREC_F16 or RS_PREC_SPLIT), coef_dev [B][2][Cin]
- * fp32 device (null: plain conv), act_in 0 / 2 (none / SiLU), weights [Cout][Cin][3][3] fp32 host.  Returns an error when the shape
- * is not eligible for that kernel. */
+ * fp32 device (null: plain conv), act_in 0 / 2 (none / SiLU), weights [Cout][Cin][3][3] fp32 host.  `ystats_dev` (may be null):
+ * [B][max(1, H*W/256)][Cout][2] fp32 device, receives the per-(image, 256-pixel slab, channel) sum / sum of squares of the stored
+ * output (the GroupNorm statistics the kernel - or, for its split-K launches on the 16x16 / 8x8 planes, the reduce kernel - leaves
+ * for the consuming GroupNorm).  Returns an error when the shape is not eligible for that kernel. */
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res,
-                       void* y, int B, int H, int W, int Cin, int Cout, int prec, void* stream);
+                       void* y, int B, int H, int W, int Cin, int Cout, int prec, float* ystats_dev, void* stream);
 /* batched NT GEMM: y[z][m][n] = scale * sum_k a[z][m][k] * b[z][n][k]  (+bias[n]) */
 int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale,
                   int in_prec, int out_prec, void* stream);
@@ -202,6 +204,12 @@ int rs_op_window_attention(const void* qkv, void* out, const float* bias_table_h
  * bproj_dev the output projection is fused as well and `res` (fp16 [B,H,W,192], may be null) is added: out = res + proj(attn) */
 int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float* bqkv_dev, const void* wproj_dev, const float* bproj_dev,
                                const void* res, void* out, const float* table_host, int B, int H, int W, int heads, int shift, void* stream);
+/* the same on split storage (RS_PREC_SPLIT): x / res / out are (hi, lo) pair tensors, wqkv_dev [576][192 hi | 192 lo] and wproj_dev
+ * [192][192 hi | 192 lo] fp16 on the device; `xcoef_dev` (may be null) is a GroupNorm affine [B][2][192] applied to x on the fly
+ * (models/swin_transformer.py:85-145,238-277 in one launch, win_attn_split.hip) */
+int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const float* bqkv_dev, const void* wproj_dev, const float* bproj_dev,
+                                     const void* res, void* out, const float* table_host, const float* xcoef_dev, int B, int H, int W, int heads,
+                                     int shift, void* stream);
 /* fused Swin MLP, fp16 device tensors: y[M][E] = res + fc2(GELU(fc1(x))) with fc1 weights [HD][E], fc2 weights [E][HD]
  * (row-major fp16, device), fp32 biases; res may be null (models/swin_transformer.py:17-33,279) */
 int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libresshift_hip.so")
-SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm4.hip", "igemm_split.hip", "swin_mlp.hip", "direct_conv.hip", "norm_attn.hip", "elementwise.hip", "engine.hip"]
-HEADERS = ["common.h", "igemm_common.h", os.path.join("..", "..", "include", "resshift_hip.h")]
+SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm4.hip", "igemm4s.hip", "igemm_split.hip", "swin_mlp.hip", "direct_conv.hip", "norm_attn.hip", "win_attn_split.hip", "elementwise.hip", "engine.hip"]
+HEADERS = ["common.h", "igemm_common.h", "igemm4_kernel.h", os.path.join("..", "..", "include", "resshift_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("RS_BUILD_ABLATE"):   # extra instantiations for the K-loop timing ablations (scripts/igemm_bench.py + RS_IGEMM_DBG)

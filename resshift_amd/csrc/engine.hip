@@ -35,6 +35,7 @@ extern "C" {
 int rs_igemm_launch(const IGemmParams* p, int in_dt, int out_dt, int nz, hipStream_t st);
 int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt);
 int rs_igemm4_pick(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC);
+int rs_igemm4_plan(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC, int* SEG, int* SK);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_groupnorm_launch(const GNParams* p, int dt, int apply_slabs, hipStream_t st);
 int rs_win_attn_launch(const WinAttnParams* p, int dt, hipStream_t st);
@@ -45,6 +46,7 @@ int rs_axpbypcz_launch(const float* x, const float* z, const float* n, float* y,
 int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st);
 int rs_win_attn_qkv_supported(int heads, int E);
 int rs_win_attn_qkv_launch(const WinAttnParams* p, hipStream_t st);
+int rs_win_attn_qkv_split_launch(const WinAttnParams* p, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                              int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st);
@@ -209,11 +211,12 @@ struct Exec {
         if (e1) (void)hipEventRecord(e1, st);
     }
     // fused qkv projection + window attention: the projection's FLOPs / compulsory bytes stay in the MFMA-family bookkeeping
-    void win_attn_qkv(const WinAttnParams& p, int E) {
+    void win_attn_qkv(const WinAttnParams& p, int E, int dt = RS_F16) {
         const double M = (double)p.B * p.H * p.W;
-        igemm_flops[0] += 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E;
-        fam_note(F_WINATTN, 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E + 2.0 * 2.0 * M * 64.0 * E);   // + QK^T and PV of the 64-token windows
-        igemm_bytes += 2.0 * (M * E * (p.res ? 3.0 : 2.0) + (p.wproj ? 4.0 : 3.0) * E * E);
+        const int sp = dt == RS_F16S;
+        igemm_flops[sp ? 2 : 0] += 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E;
+        fam_note(sp ? F_WINATTN_S : F_WINATTN, 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E + 2.0 * 2.0 * M * 64.0 * E);   // + QK^T and PV of the 64-token windows
+        igemm_bytes += (sp ? 4.0 : 2.0) * (M * E * (p.res ? 3.0 : 2.0) + (p.wproj ? 4.0 : 3.0) * E * E);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && prof->on) {
@@ -225,7 +228,8 @@ struct Exec {
             e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
             (void)hipEventRecord(e0, st);
         }
-        check(rs_win_attn_qkv_launch(&p, st), "win_attn_qkv");
+        if (sp) check(rs_win_attn_qkv_split_launch(&p, st), "win_attn_qkv_split");
+        else check(rs_win_attn_qkv_launch(&p, st), "win_attn_qkv");
         if (e1) (void)hipEventRecord(e1, st);
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
@@ -621,13 +625,16 @@ struct rs_engine {
     }
     // true when this 3x3 conv runs on the halo kernel (igemm4.hip), which can apply a GroupNorm affine + SiLU to its input
     // while the halo tile sits in LDS: the producer's raw output is read, the GroupNorm apply pass disappears
-    bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res) const {
+    // (`sk`: the halo kernel's own split-K factor for this launch - the small planes of the 16 x 16 / 8 x 8 levels run as split-K
+    // slices over the stage sequence, igemm4_kernel.h; `seg`: its tile geometry, 8 = four 8 x 8 images per tile)
+    bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res, int* sk = nullptr, int* seg = nullptr) const {
         if (w.direct || (x.dt != RS_F16 && x.dt != RS_F16S) || y.dt != x.dt || x.C != w.CinP) return false;
-        const int M = y.B * y.H * y.W;
-        if (rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * x.C, x.dt) > 1) return false;
         const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
-        int tw, bc;
-        return rs_igemm4_pick(&p, x.dt, y.dt, 1, &tw, &bc) != 0;
+        int tw, bc, sg = 0, k = 1;
+        if (!rs_igemm4_plan(&p, x.dt, y.dt, 1, &tw, &bc, &sg, &k)) return false;
+        if (sk) *sk = k;
+        if (seg) *seg = sg;
+        return true;
     }
     void conv(Exec& ex, const ConvW& w, const View& x, const View* x1, const View& y, int stride, int pad_t, int pad_l, int up,
               int act, const View* res, float out_scale = 1.f, const float* xcoef = nullptr, int xact = RS_ACT_NONE) {
@@ -637,7 +644,10 @@ struct rs_engine {
         float* partial = nullptr;
         if (!w.direct) {
             const int M = y.B * y.H * y.W;
-            splitk = rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * (x.C + C1), x.dt);
+            int sk4 = 1;
+            // the halo kernel plans its own split-K (slices of the stage sequence); everything else asks the generic planner
+            if (!x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res, &sk4)) splitk = sk4;
+            else splitk = rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * (x.C + C1), x.dt);
             if (splitk > 1) partial = (float*)ex.raw((size_t)splitk * M * w.Cout * sizeof(float));
         }
         // split storage has no two-source implicit GEMM: gather the channel concatenation once (only the first conv of the
@@ -688,8 +698,12 @@ struct rs_engine {
     void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res) {
         static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
         const int HW = y.H * y.W;
-        if (!on || ex.trace || (HW % 256) || !halo_conv(w, x, y, res)) return;
-        y.stS = HW / 256; y.stld = y.ld;
+        int sk = 1, seg = 0;
+        if (!on || ex.trace || !halo_conv(w, x, y, res, &sk, &seg)) return;
+        // tile epilogue: 256-pixel tiles of one image; split-K launches: the reduce kernel, in slabs of 256 pixels (or the whole
+        // image when it is smaller: the 8 x 8 planes)
+        if (sk > 1 ? (HW > 256 && (HW % 256)) : ((HW % 256) || seg == 8)) return;
+        y.stS = std::max(1, HW / 256); y.stld = y.ld;
         y.st = (float*)ex.raw((size_t)y.B * y.stS * y.stld * 2 * sizeof(float));
     }
     // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
@@ -784,7 +798,10 @@ struct rs_engine {
             // also apply the GroupNorm affine while they load their input, so norm1 / norm2 only produce [B][2][E] coefficients.
             static const int attn_fused = []() { const char* v = getenv("RS_ATTN_FUSED"); return v ? atoi(v) : 2; }();
             static const int gn_fold = []() { const char* v = getenv("RS_GN_FOLD"); return v ? atoi(v) : 1; }();
-            const bool fuse_qkv = attn_fused && X.dt == RS_F16 && rs_win_attn_qkv_supported(heads, E) && s.bias_n && s.qkv.wh && !ex.trace;
+            // split storage: the same fusion in win_attn_split.hip (RS_ATTN_FUSED_SPLIT=0: separate qkv GEMM, attention, projection GEMM)
+            static const int attn_fused_split = []() { const char* v = getenv("RS_ATTN_FUSED_SPLIT"); return v ? atoi(v) : 1; }();
+            const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.trace &&
+                                  ((attn_fused && X.dt == RS_F16 && s.qkv.wh) || (attn_fused_split && X.dt == RS_F16S && s.qkv.ws && s.proj.ws));
             const bool fold1 = fuse_qkv && gn_fold;
             View n;
             float* coef1 = nullptr;
@@ -796,7 +813,7 @@ struct rs_engine {
                 conv1(ex, s.qkv, n, qkv);
                 ex.tr(bp + "qkv", qkv);
             }
-            const bool fuse_proj = fuse_qkv && attn_fused >= 2 && s.proj.wh;   // ... and the output projection + shortcut as well
+            const bool fuse_proj = fuse_qkv && (X.dt == RS_F16S || (attn_fused >= 2 && s.proj.wh));   // ... and the output projection + shortcut as well
             View a, e2;
             if (fuse_proj) e2 = ex.T(X.B, X.H, X.W, E, X.dt); else a = ex.T(X.B, X.H, X.W, E, X.dt);
             if (fuse_qkv) {
@@ -805,10 +822,10 @@ struct rs_engine {
                     p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
                     p.scale = 1.0f / std::sqrt((float)(E / heads));
                     if (fold1) { p.x = e.p; p.ldx = e.ld; p.xcoef = coef1; } else { p.x = n.p; p.ldx = n.ld; }
-                    p.wqkv = s.qkv.wh; p.bqkv = s.qkv.bias;
-                    if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.wh; p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld; }
+                    p.wqkv = s.qkv.w_for(X.dt); p.bqkv = s.qkv.bias;
+                    if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.w_for(X.dt); p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld; }
                     else { p.out = a.p; p.ldo = a.ld; }
-                    ex.win_attn_qkv(p, E);
+                    ex.win_attn_qkv(p, E, X.dt);
                 }
             } else if (!ex.dry) {
                 WinAttnParams p{};
@@ -1568,7 +1585,11 @@ int rs_op_conv2d(const void* x0, const void* x1, const float* w_ref_host, const 
         p.x0 = x0; p.x1 = x1; p.w = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = C0; p.C1 = C1; p.ld0 = C0; p.ld1 = C1;
         p.B = B; p.Hs = Hs; p.Ws = Ws; p.up = up; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
         p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * Ho * Wo; p.Ktot = (int)K; p.act = act; p.out_scale = 1.f;
-        p.splitk = rs_igemm_splitk_plan(p.M, Cout, (int)K, in_prec);
+        {
+            int tw4, bc4, seg4, sk4;   // the halo kernel plans its own split-K (as Engine::conv does)
+            if (rs_igemm4_plan(&p, in_prec, out_prec, 1, &tw4, &bc4, &seg4, &sk4)) p.splitk = sk4;
+            else p.splitk = rs_igemm_splitk_plan(p.M, Cout, (int)K, in_prec);
+        }
         float* part = nullptr;
         if (p.splitk > 1) { (void)hipMalloc((void**)&part, (size_t)p.splitk * p.M * Cout * sizeof(float)); p.partial = part; }
         rc = rs_igemm_launch(&p, in_prec, out_prec, 1, st);
@@ -1592,7 +1613,11 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
     p.x0 = x0; p.w = w_packed_dev; p.bias = bias_dev; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin;
     p.B = B; p.Hs = Hs; p.Ws = Ws; p.up = up; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad; p.pad_l = pad;
     p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * Ho * Wo; p.Ktot = KH * KW * Cin; p.act = act; p.out_scale = 1.f;
-    p.splitk = rs_igemm_splitk_plan(p.M, Cout, p.Ktot, in_prec);
+    {
+        int tw4, bc4, seg4, sk4;
+        if (rs_igemm4_plan(&p, in_prec, out_prec, 1, &tw4, &bc4, &seg4, &sk4)) p.splitk = sk4;
+        else p.splitk = rs_igemm_splitk_plan(p.M, Cout, p.Ktot, in_prec);
+    }
     float* part = nullptr;
     if (p.splitk > 1) { (void)hipMalloc((void**)&part, (size_t)p.splitk * p.M * Cout * sizeof(float)); p.partial = part; }
     int rc = rs_igemm_launch(&p, in_prec, out_prec, 1, st);  // warm-up
@@ -1614,7 +1639,7 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
 // GroupNorm-affine + SiLU + 3x3 conv on the halo kernel (igemm4.hip): x raw fp16 NHWC, coef_dev [B][2][Cin] fp32 (scale row,
 // shift row) or null, weights in the reference layout on the host; fails when the shape is not eligible for that kernel
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res, void* y,
-                       int B, int H, int W, int Cin, int Cout, int prec, void* stream) {
+                       int B, int H, int W, int Cin, int Cout, int prec, float* ystats_dev, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t K = (size_t)9 * Cin, n = K * Cout;
     if (prec != RS_F16 && prec != RS_F16S) return fail("halo kernel: fp16 or split storage");
@@ -1636,10 +1661,17 @@ int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const f
     p.x0 = x; p.w = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin; p.B = B; p.Hs = H; p.Ws = W; p.up = 1; p.Ho = H; p.Wo = W;
     p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = (int)K;
     p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in;
-    int tw, bc, rc;
-    if (!rs_igemm4_pick(&p, prec, prec, 1, &tw, &bc)) rc = fail("shape is not eligible for the halo kernel");
-    else rc = rs_igemm_launch(&p, prec, prec, 1, st);
+    int tw, bc, seg, sk, rc;
+    float* part = nullptr;
+    if (!rs_igemm4_plan(&p, prec, prec, 1, &tw, &bc, &seg, &sk)) rc = fail("shape is not eligible for the halo kernel");
+    else {
+        p.splitk = sk;
+        if (sk > 1) { (void)hipMalloc((void**)&part, (size_t)sk * p.M * Cout * sizeof(float)); p.partial = part; }
+        p.ystats = ystats_dev; p.ystats_ld = Cout;
+        rc = rs_igemm_launch(&p, prec, prec, 1, st);
+    }
     (void)hipStreamSynchronize(st);
+    if (part) (void)hipFree(part);
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);
     return rc;
@@ -1721,6 +1753,29 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
     p.wproj = wproj_dev; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
     const int rc = rs_win_attn_qkv_launch(&p, st);
     if (rc) fail("fused qkv + window attention launch rejected the shape (fp16, 6 heads of 32 only)");
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(dn);
+    return rc;
+}
+
+int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const float* bqkv_dev, const void* wproj_dev, const float* bproj_dev,
+                                     const void* res, void* out, const float* table_host, const float* xcoef_dev, int B, int H, int W, int heads,
+                                     int shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> bn((size_t)heads * 64 * 64);
+    for (int h = 0; h < heads; ++h)
+        for (int i = 0; i < 64; ++i)
+            for (int j = 0; j < 64; ++j) {
+                const int idx = ((i >> 3) - (j >> 3) + 7) * 15 + ((i & 7) - (j & 7) + 7);
+                bn[((size_t)h * 64 + i) * 64 + j] = table_host[(size_t)idx * heads + h];
+            }
+    float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
+    WinAttnParams p{};
+    p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
+    p.x = x; p.wqkv = wqkv_dev; p.bqkv = bqkv_dev; p.ldx = heads * 32; p.xcoef = xcoef_dev;
+    p.wproj = wproj_dev; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
+    const int rc = rs_win_attn_qkv_split_launch(&p, st);
+    if (rc) fail("fused split qkv + window attention launch rejected the shape (split storage, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
     (void)hipFree(dn);
     return rc;

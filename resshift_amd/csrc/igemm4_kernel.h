@@ -1,0 +1,617 @@
+// Halo-tile implicit GEMM for the 3x3 / stride-1 / pad-1 convolutions (fp16 storage), fourth generation.
+//
+// igemm2 / igemm3 gather the pixel operand once PER FILTER TAP: a 3x3 conv moves every input pixel nine times from L2 into
+// LDS, and the GroupNorm + SiLU in front of the conv (models/unet.py:128-147, ldm/modules/diffusionmodules/model.py:129-137)
+// needs its own read + write pass over the tensor because LDS-DMA data never passes through registers.  Here the loop nest
+// is turned inside out:
+//     for 64-channel chunk c:   halo tile (TH+2) x (TW+2) pixels x 64 channels  -> LDS  ONCE        (LDS-DMA)
+//                               [GroupNorm affine (+FiLM) + SiLU applied IN LDS, once per element]   (optional)
+//         for tap (ky,kx):      weight tile BC x 64 of W[:, tap, c]            -> LDS ring          (LDS-DMA)
+//                               MFMA: the pixel fragments are the SAME halo rows, read at offset ky*(TW+2)+kx
+//   * pixel traffic L2 -> LDS drops from 9 x 256 rows to (TH+2)(TW+2) = 396 rows per chunk (5.8 x less at TW = 64); the weight
+//     tile is amortised over 256 pixels (igemm2: 128);
+//   * the conv reads the RAW producer output: the GroupNorm apply pass (one read + one write of the whole tensor per
+//     GroupNorm) disappears, only the statistics pass remains.  The affine is applied exactly where gn_apply_kernel applies it
+//     (fp32 fma, SiLU, round to fp16), so results are bit-identical to the two-kernel path; halo rows outside the image stay
+//     exact zeros (the conv pads the NORMALISED tensor);
+//   * 128-byte LDS rows with the usual (chunk ^ row & 7) swizzle are conflict-free for ANY 16 consecutive rows, so the shifted
+//     fragment reads cost no more than the aligned ones.
+// Tile: 256 output pixels (TH x TW = 4 x 64 or 8 x 32, one image) x BC channels, 8 waves as 4 pixel-waves x 2 channel-waves
+// (wave tile 64 x BC/2), one workgroup per CU; LDS: 2 halo buffers (chunk c computes while chunk c+1 arrives, spread over the
+// taps) + 2 weight slots.  Epilogue as igemm2 (bias, activation, residual, fp16 transposition through LDS).
+//
+// SPLIT = true: the same kernel for split storage (RS_F16S: (hi, lo) fp16 pairs, common.h).  A chunk is 32 channels and an LDS
+// row holds [32 ch hi | 32 ch lo] - again 128 bytes / 8 sixteen-byte positions with the same swizzle, so the LDS image, the
+// LDS-DMA pieces and every fragment address are those of the fp16 kernel; position q of a row is fetched from the hi (q < 4) or
+// the lo plane of the pixel record / weight row.  What were the two k-steps of a stage are now the hi and the lo fragments of ONE
+// k-step: acc += (2^11 Wh).Xh + Wh.Xl + Wl.Xh (three MFMAs, ONE accumulator: the hi weight fragment is scaled by 2^11 with
+// v_pk_mul_f16 - exact for |w| < 32, checked when the weights are packed - instead of keeping a second accumulator set), and the
+// epilogue multiplies by 2^-11.  The GroupNorm pass joins, transforms and re-splits the pairs.
+// SEG > 0 (igemm4s.hip): small planes.  The 8 x 32-pixel tile is cut into 32 / SEG segments of SEG pixels, each with its own halo
+// columns and separated by ONE shared zero column ([pad | seg 0 | pad | seg 1 | ... | pad]: 1 + (32 / SEG)(SEG + 1) <= 40 columns, the
+// halo buffer of the 8 x 32 geometry): SEG = 8: four IMAGES of an 8 x 8 plane side by side; SEG = 16: the two 8-row halves of ONE 16 x 16
+// image (each half brings its own top / bottom halo rows).  That puts the 16 x 16 / 8 x 8 UNet levels - latency chains on the generic
+// kernels: one LDS-DMA round trip per k-step (profiles/r2_igemm4_ablation.txt §7, §8) - on the halo kernel's schedule (halo once per
+// chunk, three weight slots, GroupNorm fold).  Their few tiles fill the chip by SPLIT-K OVER STAGES: grid.z slices the (chunk, tap)
+// stage sequence [0, 9 nch) into contiguous ranges - a slice may start or end in the middle of a chunk - and every slice writes an fp32
+// partial slab that splitk_reduce_kernel / splitk_reduce_stats_kernel finishes (bias, activation, residual, storage conversion,
+// optional GroupNorm statistics of the stored output).
+#pragma once
+#include "igemm_common.h"
+#include <type_traits>
+
+namespace {
+
+using namespace igemm_detail;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// NB: keep the LDS-DMA builtin inside a plain __device__ function (see igemm2.hip)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
+}
+
+// k-step 1 of a fragment address (chunk index ^ 4 = byte ^ 64), computed where it is used: as plain C++ the compiler hoists all
+// twelve variants out of the tap loop and the kernel spills
+__device__ __forceinline__ int xor64(int v) {
+    int r;
+    asm volatile("v_xor_b32 %0, 64, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+__device__ long long g_ig4_clk[4 * 8192];   // per workgroup: cycle counter at kernel start / K loop start / K loop end / kernel end (ablate builds)
+#endif
+// ABL (builds with -DRS_SPLIT_ABLATE only, RS_IGEMM4_ABL=n selects): timing ablations, results wrong: bit 0 = no weight loads
+// after the first two stages, bit 1 = no halo loads after chunk 0, bit 2 = no MFMAs
+template <int TW, int BC, bool SPLIT, int SEG = 0, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
+    static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16)), "segmented tiles use the 8 x 32 geometry");
+    constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
+    // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
+    // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
+    constexpr int TH = 256 / TW, HWD = (TW + 2 + 7) / 8 * 8, HROWS = (TH + 2) * HWD, HROWS_P = HROWS;
+    constexpr int XBUF = HROWS_P * 128;
+    constexpr int WSLOT = BC * 128;
+    constexpr int WBASE = 2 * XBUF;
+    // weight ring: three slots wherever 160 KB allow it (tile s+2 is requested at stage s and has two stages to land: with two
+    // slots the L2 round trip of tile s+1 - ~1 us under load against a 1.1 us stage - shows up as 8 - 14 % of the kernel time,
+    // profiles/r2_igemm4_ablation.txt); (TW = 64, BC = 160) and BC = 192 keep two
+    constexpr int NSLOT = (2 * XBUF + 3 * WSLOT <= 160 * 1024) ? 3 : 2;
+    constexpr int FP = 4, FC = BC / 32;
+    constexpr int XPIECES = HROWS_P / 8;        // 1 KB LDS-DMA pieces (8 halo rows x 128 B) of one chunk
+    constexpr int XPW = (XPIECES + 7) / 8;      // pieces per wave (wave w owns pieces w, w+8, ...)
+    constexpr int RWF = BC / 64, RWP = BC % 64, RW = RWF + (RWP ? 1 : 0);
+    constexpr int NCELL = (HROWS_P * 8 + 511) / 512;   // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
+    static_assert(XPW <= 8 && RWP % 8 == 0 && 2 * XBUF + NSLOT * WSLOT <= 160 * 1024, "tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x] = clock64();
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wp = wave & 3, wc = wave >> 2;
+    const int rr = 8 * wave + (lane >> 3);
+    const int kcp = (lane & 7) ^ ((lane >> 3) & 7);    // source K-chunk of this lane (swizzle on the source side)
+    const bool wpart = !RWP || wave < RWP / 8;
+
+    // ---- tile decode: channel tiles of one pixel tile are adjacent (they share the halo in L2)
+    const int nby = (p.Cout + BC - 1) / BC;
+    const int txb_n = p.Wo / TW, tyb_n = p.Ho / TH;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = tile % nby; tile /= nby;
+    // SEG: one tile = four images of an 8 x 8 plane (SEG = 8) or one 16 x 16 image (SEG = 16); b = first image of the tile
+    const int txb = SEG ? 0 : tile % txb_n;
+    if (!SEG) tile /= txb_n;
+    const int tyb = SEG ? 0 : tile % tyb_n;
+    const int b = SEG ? (SEG == 8 ? 4 * tile : tile) : tile / tyb_n;
+    const int n0 = nb * BC, y0 = tyb * TH, x0 = txb * TW;
+    const int Cin = p.C0;
+    // (scalars used inside the loops / lambdas are copied out of the by-value parameter block: a lambda capture of `p` itself
+    // makes the compiler park the whole struct in scratch memory, and scratch loads inside the K loop drain the DMA queue)
+    const float* const xcoef = p.xcoef;
+    const int xact = p.xact, Hs = p.Hs, Ws = p.Ws;
+    // halo row hr of the tile -> source pixel (image index in `img`); false: zero padding / separator column / outside the image
+    auto halo_src = [&](int hr, unsigned& pix, int& img) -> bool {
+        const int hy = hr / HWD, hx = hr - hy * HWD;
+        if constexpr (SEG == 0) {
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            img = b;
+            pix = (unsigned)((b * Hs + y) * Ws + x);
+            return hr < HROWS && hx < TW + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        } else {
+            const int q = hx - 1, sg = q / (SEG + 1), xin = q - sg * (SEG + 1);     // (q = -1: sg = 0, xin = -1)
+            const int y = (SEG == 16 ? 8 * sg : 0) - 1 + hy;
+            img = b + (SEG == 8 ? sg : 0);
+            pix = (unsigned)((img * Hs + y) * Ws + xin);
+            return hr < HROWS && hx >= 1 && (unsigned)xin < (unsigned)SEG && sg < 32 / SEG && (unsigned)y < (unsigned)Hs;
+        }
+    };
+
+    constexpr unsigned INV = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // Refill addresses are recomputed where they are used (a dozen VALU instructions per LDS-DMA piece): kept in registers across
+    // the K loop they push the kernel over 256 VGPRs, and a spilled value comes back through a scratch load - a VMEM access whose
+    // wait also drains the DMA queue.
+    const int Cout = p.Cout, Ktot = p.Ktot, ld0 = p.ld0;
+    auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w+8, ...)
+        if (wave + 8 * k >= XPIECES) return;                       // wave-uniform
+        const int hr = 8 * (wave + 8 * k) + (lane >> 3);
+        unsigned pix; int img;
+        const bool inside = halo_src(hr, pix, img);
+        // source of LDS position (lane & 7) of this row = logical chunk kcp: fp16: channels 8 kcp ..; split: plane kcp >> 2
+        // (0 = hi, 1 = lo, `ld0` halfs further in the pixel record), channels 8 (kcp & 3) ..
+        const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
+        const bool ok = inside && cb < (unsigned)Cin;
+        const unsigned off = SPLIT ? pix * (unsigned)ld0 * 4u + (kcp >> 2) * (unsigned)ld0 * 2u + cb * 2u : pix * (unsigned)ld0 * 2u + cb * 2u;
+        lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? off : INV);
+    };
+    auto issue_w = [&](int s, int slot) {   // weight tile of stage s = (chunk s / 9, tap s % 9) -> ring slot s % NSLOT (passed in)
+        const int c = s / 9, tap = s - c * 9;
+        const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
+        // weight rows: fp16 [K]; split [K hi | K lo]
+        const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u + (SPLIT ? (kcp >> 2) * (unsigned)Ktot * 2u : 0u);
+        char* sbase = smem + WBASE + slot * WSLOT + (8 * wave) * 128;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            if (RWP && i == RW - 1 && !wpart) continue;
+            const int n = n0 + 64 * i + rr;
+            const bool ok = 64 * i + rr < BC && n < Cout && cb < (unsigned)Cin;
+            lds_dma16(rw, sbase + (64 * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + kb : INV);
+        }
+    };
+
+    // ---- fragment addressing
+    const int swz0 = ((lg ^ (lr & 7)) << 4), swz1 = (((4 + lg) ^ (lr & 7)) << 4);
+    const int la = (wc * (BC / 2) + lr) * 128;
+    int xfo[FP][3];   // LDS byte offset (k-step 0; k-step 1 = ^ 64) of (fragment j, lane) in the CURRENT halo buffer for kx = 0..2, ky = 0
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+        const int ty = TW == 64 ? wp : 2 * wp + (j >> 1);
+        const int tx = TW == 64 ? 16 * j : 16 * (j & 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            // (SEG: pixel column tx + lr of the tile sits (tx + lr) / SEG separator columns further right)
+            const int hr = ty * HWD + tx + lr + (SEG ? (tx + lr) / SEG : 0) + kx;
+            xfo[j][kx] = hr * 128 + ((lg ^ (hr & 7)) << 4);
+        }
+    }
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- in-LDS GroupNorm (+FiLM) + activation of one halo chunk: thread t owns the 16-byte cells t, t+512, ...; their
+    // channel group (cell & 7) ^ (row & 7) is the same for all of them, so 16 coefficients per chunk stay in registers
+    const int cg = (tid & 7) ^ ((tid >> 3) & 7);
+    unsigned cell_in = 0;   // bit k: cell k of this thread is a pixel inside the image (the others must stay exact zeros)
+#pragma unroll
+    for (int k = 0; k < NCELL; ++k) {
+        unsigned pix; int img;
+        if (halo_src((tid >> 3) + 64 * k, pix, img)) cell_in |= 1u << k;
+    }
+    // split storage: thread t owns, in rows (t >> 2) + 128 k, the position pair (t & 3, (t & 3) + 4) = the hi and the lo half (in
+    // swizzle-dependent order) of ONE 8-channel group
+    const int sp_hi = ((tid & 3) ^ ((tid >> 2) & 7)) < 4 ? (tid & 3) : (tid & 3) + 4;   // position holding the hi halves
+    const int sp_cg = ((tid & 3) ^ ((tid >> 2) & 7)) & 3;                                 // channel group inside the 32-channel chunk
+    unsigned sp_in = 0;
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+            unsigned pix; int img;
+            if (halo_src((tid >> 2) + 128 * k, pix, img)) sp_in |= 1u << k;
+        }
+    }
+    auto apply_split = [&](int c, auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const float* sc = xcoef + (long long)b * 2 * Cin + c * 32 + sp_cg * 8;
+        f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
+        f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        char* xb = smem + (c & 1) * XBUF + (tid >> 2) * 128;
+#pragma unroll
+        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+            if (!((sp_in >> k) & 1)) continue;
+            if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
+                const int hr = (tid >> 2) + 128 * k, hx = hr % HWD;
+                const float* si = sc + (long long)((hx - 1) / (SEG + 1)) * 2 * Cin;
+                a0 = *(const f32x4*)si; a1 = *(const f32x4*)(si + 4); d0 = *(const f32x4*)(si + Cin); d1 = *(const f32x4*)(si + Cin + 4);
+            }
+            f16x8* ch_ = (f16x8*)(xb + k * 16384 + sp_hi * 16);
+            f16x8* cl_ = (f16x8*)(xb + k * 16384 + (sp_hi ^ 4) * 16);
+            f16x8 vh = *ch_, vl = *cl_;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = fmaf(rs_join(vh[e], vl[e]), e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? d0[e & 3] : d1[e & 3]);
+                // SiLU with v_exp / v_rcp (1 ulp each): fp32-class, a fifth of the IEEE-division sequence
+                const float u = ACT == RS_ACT_SILU ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : t;
+                f16 hh, ll;
+                rs_split(u, hh, ll);
+                vh[e] = hh; vl[e] = ll;
+            }
+            *ch_ = vh; *cl_ = vl;
+        }
+    };
+    auto apply = [&](int c, auto act_tag) __attribute__((always_inline)) {   // (not inlined, its closure object lives in scratch memory)
+        constexpr int ACT = decltype(act_tag)::value;
+        const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
+        const float* sc = xcoef + (long long)b * 2 * Cin + ch;
+        f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
+        f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        char* xb = smem + (c & 1) * XBUF + tid * 16;
+#pragma unroll
+        for (int k = 0; k < NCELL; ++k) {
+            if (!((cell_in >> k) & 1)) continue;
+            if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
+                const int hr = (tid >> 3) + 64 * k, hx = hr % HWD;
+                const float* si = sc + (long long)((hx - 1) / (SEG + 1)) * 2 * Cin;
+                a0 = *(const f32x4*)si; a1 = *(const f32x4*)(si + 4); d0 = *(const f32x4*)(si + Cin); d1 = *(const f32x4*)(si + Cin + 4);
+            }
+            f16x8* cell = (f16x8*)(xb + k * 8192);
+            f16x8 v = *cell;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (f16)rs_act_t<ACT, true>(fmaf((float)v[e], a0[e], d0[e]));
+                v[4 + e] = (f16)rs_act_t<ACT, true>(fmaf((float)v[4 + e], a1[e], d1[e]));
+            }
+            *cell = v;
+        }
+    };
+
+    const int nch = (Cin + KC - 1) / KC, nst = nch * 9;
+    // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
+    // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
+    // fragment register sets carried across the nine unrolled taps - igemm3's schedule - needs > 256 VGPRs here: 160 spilled
+    // registers, 557 instead of 810 TFLOP/s on the layer mix.)
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 1] = clock64();
+#endif
+    // split-K over stages: this workgroup's slice [s_beg, s_end) of the (chunk, tap) sequence (the whole sequence without split-K);
+    // it may begin / end in the middle of a chunk.  (The planner leaves no slice empty.)
+    const int zsl = blockIdx.z;
+    int s_beg = 0, s_end = nst;
+    if (p.splitk > 1) {
+        const int per = (nst + p.splitk - 1) / p.splitk;
+        s_beg = min(nst, zsl * per);
+        s_end = min(nst, s_beg + per);
+    }
+    const int c_beg = s_beg / 9, c_last = (s_end - 1) / 9;
+#pragma unroll
+    for (int k = 0; k < XPW; ++k) issue_x(c_beg, k);
+    issue_w(s_beg, NSLOT == 3 ? s_beg % 3 : (s_beg & 1));
+    if (NSLOT == 3 && s_beg + 1 < s_end) issue_w(s_beg + 1, (s_beg + 1) % 3);
+    if (c_beg & 1) {   // the first chunk of the slice sits in halo buffer 1
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xfo[j][q] += XBUF;
+    }
+    for (int c = c_beg; c <= c_last; ++c) {
+        const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
+        const int t_first = c == c_beg ? s_beg - 9 * c_beg : 0;   // first tap of this chunk inside the slice
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = c * 9 + tap;
+            if (s < s_beg || s >= s_end) continue;   // (workgroup-uniform)
+            // weight tile s (and every halo piece issued before it) has landed: with three slots only the loads of tile s+1 - the
+            // youngest RW (waves that also own a partial row group) or RWF ones of this wave - may still be in flight
+            if (NSLOT == 3 && s + 1 < s_end) {
+                if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tap == t_first) {
+                if (xcoef) {
+                    if constexpr (SPLIT) {
+                        if (xact == RS_ACT_SILU) apply_split(c, std::integral_constant<int, RS_ACT_SILU>{});
+                        else apply_split(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    } else {
+                        if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{});
+                        else apply(c, std::integral_constant<int, RS_ACT_NONE>{});
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (c > c_beg) {   // the fragment offsets move over to the other halo buffer
+                    const int flip = (c & 1) ? XBUF : -XBUF;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) xfo[j][q] += flip;
+                }
+            }
+            // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
+            // (a slice that enters the chunk at tap t_first > 0 has 9 - t_first stages for the XPW pieces: the rest goes with tap 8)
+            if (c < c_last && !(ABL & 2)) {
+                const int k0 = tap - t_first;
+                if (k0 < XPW) issue_x(c + 1, k0);
+                if (tap == 8)
+                    for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
+            }
+            // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
+            if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+            const char* wb = smem + WBASE + (NSLOT == 3 ? tap % 3 : (s & 1)) * WSLOT + la;
+            const int ky = tap / 3, kx = tap % 3;
+            if constexpr (SPLIT) {
+                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
+                    bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                    al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && !two) break;
+                const int sw = ks ? swz1 : swz0;
+                f16x8 a[FC], bf[FP];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) {
+                        if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 2] = clock64();
+#endif
+    // ---------------------------------------------------------------- epilogue
+    // (the barrier that ends the K loop comes after the residual loads below: their latency - the 4 x FC loads of a lane used to
+    // be issued per channel fragment, five round trips to L2 in a row, 8 - 10 k cycles of a 60 - 120 k cycle workgroup - overlaps it)
+    // global pixel index of row r (0..63) of this wave's pixel tile
+    auto pixel = [&](int r) -> long long {
+        const int ty = TW == 64 ? wp : 2 * wp + (r >> 5);
+        const int tx = TW == 64 ? r : (r & 31);
+        if constexpr (SEG == 8) return ((long long)(b + (tx >> 3)) * 8 + ty) * 8 + (tx & 7);           // image b + segment, 8 x 8 plane
+        if constexpr (SEG == 16) return ((long long)b * 16 + ty + 8 * (tx >> 4)) * 16 + (tx & 15);      // rows 8 .. 15 in segment 1
+        return ((long long)b * p.Ho + y0 + ty) * p.Wo + x0 + tx;
+    };
+    if (p.splitk > 1) {
+        // split-K slice: raw fp32 partial sums (split storage: the accumulator carries 2^11 x the sum); scale / bias / activation /
+        // residual / storage conversion are applied by the reduce kernel.  No LDS is touched: no barrier with the waves still looping.
+        float* part = p.partial + (long long)zsl * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const long long m = pixel(j * 16 + lr);
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+                if (n < p.Cout) *(f32x4*)(part + m * p.Cout + n) = SPLIT ? acc[i][j] * RS_LO_INV : acc[i][j];
+            }
+        }
+        return;
+    }
+    constexpr int ROWB = (BC / 2) * 2 + 16;
+    constexpr int CPR = (BC / 2) / 8;
+    constexpr int NITEM = 64 * CPR;
+    char* stg = smem + wave * 64 * ROWB;
+    f16* y = (f16*)p.y;
+    const f16* res = (const f16*)p.res;
+    const bool res_ok = res != nullptr;
+    long long mres[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) mres[j] = pixel(j * 16 + lr) * p.ldres * (SPLIT ? 2 : 1);
+    f32x4 bvs[FC];
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+        const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
+        bvs[i] = p.bias ? *(const f32x4*)(p.bias + min(n, p.Cout - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // per-channel statistics of the stored output for the consuming GroupNorm (IGemmParams::ystats): lane (lr, lg) accumulates its
+    // 4 channels of every channel fragment over its FP pixel fragments, then the 16 `lr` lanes are reduced with xor-shuffles
+    float* const ystats = p.ystats;
+    // (LDS: the staging tiles end below 8 * 64 * ROWB <= 106 KB; the partials sit behind them)
+    float* const sb = (float*)(smem + 8 * 64 * ROWB);
+    // wave-level sum of one (channel fragment, register) column over the 16 pixel lanes -> LDS
+    auto stats_put = [&](int i, int r, float a, float q) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (lr == 0) { sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
+    };
+    auto stats_out = [&]() {   // the four pixel-waves' partials -> one pair per channel of the tile -> global
+        __syncthreads();
+        if (tid < BC && n0 + tid < p.Cout) {
+            const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2 + 1]; }
+            // (SEG = 16: the tile IS the image; SEG = 8 never produces statistics here - four images per tile)
+            float* dst = ystats + ((SEG ? (long long)b : (long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + tid) * 2;
+            dst[0] = a; dst[1] = q;
+        }
+    };
+    if constexpr (SPLIT) {
+        // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
+        const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
+        const int act = p.act, ldres = p.ldres;
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+        // (split storage: all FC fragment rows at once would need 80 registers next to the 80 accumulators)
+        f16x4 rh[2][FP], rl[2][FP];   // residual of channel fragment i + 1 in flight while fragment i is finished
+        auto load_res = [&](int i) __attribute__((always_inline)) {
+            const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) { rh[i & 1][j] = *(const f16x4*)(res + mres[j] + nr); rl[i & 1][j] = *(const f16x4*)(res + mres[j] + ldres + nr); }
+        };
+        if (res_ok) load_res(0);
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            if (res_ok && i + 1 < FC) load_res(i + 1);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                f32x4 v = acc[i][j] * osc + bvs[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (act == RS_ACT_SILU) v[r] = rs_silu(v[r]); else if (act == RS_ACT_GELU) v[r] = rs_gelu(v[r]);
+                    if (res_ok) v[r] += rs_join(rh[i & 1][j][r], rl[i & 1][j][r]);
+                }
+                acc[i][j] = v;
+            }
+            if (ystats) {   // (the stored pair reproduces v to 2^-23)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = 0.f, q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) { a += acc[i][j][r]; q = fmaf(acc[i][j][r], acc[i][j][r], q); }
+                    stats_put(i, r, a, q);
+                }
+            }
+        }
+        if (ystats) stats_out();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f16 hh, ll; rs_split(acc[i][j][r], hh, ll); h[r] = half ? ll : hh; }
+                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                }
+            __syncthreads();
+            for (int idx = lane; idx < NITEM; idx += 64) {
+                const int row = idx / CPR, c8 = idx - row * CPR;
+                const int n = n0 + wc * (BC / 2) + c8 * 8;
+                if (n >= p.Cout) continue;
+                *(uint4*)(y + pixel(row) * p.ldy * 2 + half * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+            }
+            __syncthreads();
+        }
+    } else {
+        auto run = [&](auto res_tag) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(res_tag)::value;
+        f16x4 rv[FC][FP];   // the residual of the whole wave tile, all loads in flight together
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int nr = min(n0 + wc * (BC / 2) + i * 16 + lg * 4, p.Cout - 4);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) rv[i][j] = *(const f16x4*)(res + mres[j] + nr);
+            }
+        }
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+        auto finish = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    f32x4 v = acc[i][j] * p.out_scale + bvs[i];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                    }
+                    f16x4 h;
+                    h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
+                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)h[r]; s1[r] += f; s2[r] = fmaf(f, f, s2[r]); }   // of the STORED value
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ystats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stats_put(i, r, s1[r], s2[r]);
+                }
+            }
+        };
+        if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
+        else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
+        else finish(std::integral_constant<int, RS_ACT_NONE>{});
+        };
+        if (res_ok) run(std::true_type{}); else run(std::false_type{});
+        if (ystats) stats_out();
+        __syncthreads();
+        for (int idx = lane; idx < NITEM; idx += 64) {
+            const int row = idx / CPR, c8 = idx - row * CPR;
+            const int n = n0 + wc * (BC / 2) + c8 * 8;
+            if (n >= p.Cout) continue;
+            *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+        }
+    }
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+    if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 3] = clock64();
+#endif
+}
+
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+}  // namespace
+// ablate builds: mean cycles of the three kernel phases over the first `nwg` workgroups of the last igemm4 launch
+extern "C" int rs_igemm4_phase_cycles(int nwg, double* out3) {
+    static long long h[4 * 8192];
+    if (nwg < 1 || nwg > 8192) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ig4_clk), sizeof(long long) * 4 * nwg) != hipSuccess) return -1;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    for (int i = 0; i < nwg; ++i)
+        for (int k = 0; k < 3; ++k) out3[k] += (double)(h[4 * i + k + 1] - h[4 * i + k]) / nwg;
+    return 0;
+}
+namespace {
+#endif
+
+template <int TW, int BC, bool SPLIT, int SEG = 0>
+hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
+    constexpr int TH = 256 / TW;
+    constexpr size_t xbuf = (size_t)((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128;
+    constexpr size_t lds = 2 * xbuf + ((2 * xbuf + 3 * BC * 128 <= 160 * 1024) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
+    const int tiles = (SEG == 8 ? p.B / 4 : SEG == 16 ? p.B : p.B * (p.Ho / TH) * (p.Wo / TW)) * ((p.Cout + BC - 1) / BC);
+    const int sk = p.splitk > 1 ? p.splitk : 1;
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const size_t esz = SPLIT ? 4 : 2;
+    const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * esz, wb = (size_t)p.Cout * p.Ktot * esz;
+    if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+#if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
+    if constexpr (!SPLIT && BC == 160 && SEG == 0) {
+        static const int abl = []() { const char* v = getenv("RS_IGEMM4_ABL"); return v ? atoi(v) : 0; }();
+#define RS_ABL4_CASE(A)                                                                                                              \
+    if (abl == A) {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, 0, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, 0, A>), dim3(tiles), dim3(512), lds, st, p);                                    \
+        return hipGetLastError();                                                                                                      \
+    }
+        RS_ABL4_CASE(1) RS_ABL4_CASE(2) RS_ABL4_CASE(3) RS_ABL4_CASE(4) RS_ABL4_CASE(7)
+#undef RS_ABL4_CASE
+    }
+#endif
+    hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG>), dim3(tiles, 1, sk), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace

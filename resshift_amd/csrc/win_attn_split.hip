@@ -1,0 +1,339 @@
+// Fused Swin window attention for SPLIT storage (RS_F16S, common.h): GroupNorm affine (norm1) + qkv Linear + W-MSA / SW-MSA +
+// output projection + shortcut in ONE launch, every product formed from (hi, lo) fp16 pairs with three fp16 MFMAs, i.e. the
+// fp32-class counterpart of win_attn_qkv_kernel (norm_attn.hip).  Replaces, per SwinTransformerBlock (models/swin_transformer.py:
+// 85-145, 238-277): the GroupNorm apply pass, the qkv implicit GEMM (its [M][3E] split tensor is 302 MB at batch 32 on the 64 x 64
+// level: written once, read once), win_attn_split_kernel and the projection GEMM with its residual.
+//
+// One workgroup per 8 x 8 window, one wave per head (6 heads of 32: every shipped config).
+//   1. the window's 64 tokens -> LDS by LDS-DMA, hi plane and lo plane in the row / swizzle format of the implicit-GEMM kernels
+//      (roll + window_partition folded into the addressing); with `xcoef` the GroupNorm affine is applied there (join, fma, split);
+//   2. wave h projects them with ITS 96 rows of the qkv weight (fragments straight from L2 in MFMA A-operand layout):
+//      acc = (2^11 Wh).Xh + Wh.Xl + Wl.Xh in ONE accumulator (the 2^11 scaling of the hi fragment is exact for |w| < 32, checked when
+//      the weights are packed - igemm4.hip uses the same form), bias pre-scaled in the accumulator; q and k stay in registers as (hi,
+//      lo) fragments - the accumulator layout IS the attention operand layout - and V^T goes through LDS;
+//   3. S^T = Kh Qh^T + 2^-11 (Kh Ql^T + Kl Qh^T), + relative position bias + shift mask, softmax in fp32 (expf, IEEE division),
+//      O^T = V^T P with P split on the fly (as win_attn_split_kernel);
+//   4. the heads' results meet in LDS (the token tile's space, same format) and wave h produces output features 32h .. 32h + 31 of
+//      the projection, adds the shortcut and stores the (hi, lo) pair.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr3_t;
+__device__ __forceinline__ void lds_dma16_ws(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr3_t)lds, 16, voff, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p, unsigned x_bytes) {
+    constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
+    constexpr int XS_STAGE = NT * 128;          // 64 token rows x 128 B per 64-wide K stage
+    constexpr int XS_PLANE = 3 * XS_STAGE;      // hi (or lo) plane of the token tile
+    constexpr int VT_HEAD = 2 * HD * VP;        // halfs: [HD][VP] hi, then [HD][VP] lo of one head
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nwx = p.W / WS;
+    const int b = blockIdx.y;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    f16* vth = (f16*)(smem + 2 * XS_PLANE) + (size_t)h * VT_HEAD;
+    f16* vtl = vth + HD * VP;
+    const int shift = p.shift, H = p.H, W = p.W;
+    auto pixel = [&](int t) -> long long {
+        int sy = wy * WS + (t >> 3) + shift; if (sy >= H) sy -= H;
+        int sx = wx * WS + (t & 7) + shift; if (sx >= W) sx -= W;
+        return ((long long)b * H + sy) * W + sx;
+    };
+    // ---- tokens -> LDS: 2 planes x 3 K stages x 8 row groups = 48 LDS-DMA instructions, 8 per wave
+    {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+        const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int it = h * 8 + q, plane = it / 24, r24 = it - plane * 24, st = r24 >> 3, grp = r24 & 7;
+            // pixel record [ldx halfs hi | ldx halfs lo]
+            const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldx * 2 + plane * p.ldx + st * 64 + kcp * 8) * 2u;
+            lds_dma16_ws(rx, smem + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
+        }
+    }
+    const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
+    // one projection pass over the token tile: 32 output features starting at weight row n0 (rows [K hi | K lo], K = E) ->
+    // acc[2 feature frags][4 token frags], final values (bias added, 2^-11 applied)
+    // The 32 weight rows of a pass are fetched from L2 in ONE burst (24 sixteen-byte loads per lane, 96 VGPRs) in front of the MFMAs: one
+    // exposed L2 round trip per pass; fetched k-step by k-step next to their MFMAs they were six round trips in a row (27.7 ms per
+    // parity pass for this kernel, profiles/r3_*).
+    auto load_w = [&](const f16* wsrc, int n0, f16x8 (&wh)[2][KS], f16x8 (&wl)[2][KS]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const f16* wr = wsrc + (long long)(n0 + 16 * f + lr) * (2 * E) + lg * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wh[f][ks] = *(const f16x8*)(wr + ks * 32);
+                wl[f][ks] = *(const f16x8*)(wr + E + ks * 32);
+            }
+        }
+    };
+    auto project = [&](const f16x8 (&wh)[2][KS], const f16x8 (&wl)[2][KS], const float* bias, int n0, f32x4 (&acc)[2][4]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const f32x4 bv = *(const f32x4*)(bias + n0 + 16 * f + 4 * lg) * RS_LO_SCALE;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[f][fi] = bv;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 xh[4], xl[4];
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const char* xr = smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1];
+                xh[fi] = *(const f16x8*)xr;
+                xl[fi] = *(const f16x8*)(xr + XS_PLANE);
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const f16x8 ws = wh[f][ks] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws, xh[fi], acc[f][fi], 0, 0, 0);
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[f][ks], xl[fi], acc[f][fi], 0, 0, 0);
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[f][ks], xh[fi], acc[f][fi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[f][fi] = acc[f][fi] * RS_LO_INV;
+    };
+    // accumulator pair of a token fragment -> the 8 head-dim values of that token as (hi, lo) MFMA operands
+    auto pack = [&](const f32x4 (&acc)[2][4], f16x8 (&oh)[4], f16x8 (&ol)[4]) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, c;
+                rs_split(acc[0][fi][r], a, c); oh[fi][r] = a; ol[fi][r] = c;
+                rs_split(acc[1][fi][r], a, c); oh[fi][4 + r] = a; ol[fi][4 + r] = c;
+            }
+    };
+    const f16* wq = (const f16*)p.wqkv;
+    f16x8 wfh[2][KS], wfl[2][KS];
+    load_w(wq, h * HD, wfh, wfl);     // q_h weights: requested together with the token tile, one L2 round trip for both
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // the window's tokens are in LDS
+    if (p.xcoef) {
+        // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c] on the joined value, re-split.  64 rows x 24 chunks of 8
+        // channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
+        const float* sc = p.xcoef + (long long)b * 2 * E;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int item = tid + 384 * q;              // 0 .. 1535
+            const int st = item >> 9, t = (item >> 3) & 63, ps = item & 7;
+            const int c0 = st * 64 + ((ps ^ (t & 7)) << 3);
+            f16x8* ch_ = (f16x8*)(smem + st * XS_STAGE + t * 128 + ps * 16);
+            f16x8* cl_ = (f16x8*)(smem + XS_PLANE + st * XS_STAGE + t * 128 + ps * 16);
+            f16x8 vh = *ch_, vl = *cl_;
+            const f32x4 a0 = *(const f32x4*)(sc + c0), a1 = *(const f32x4*)(sc + c0 + 4);
+            const f32x4 d0 = *(const f32x4*)(sc + E + c0), d1 = *(const f32x4*)(sc + E + c0 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f16 a, c;
+                rs_split(fmaf(rs_join(vh[e], vl[e]), e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? d0[e & 3] : d1[e & 3]), a, c);
+                vh[e] = a; vl[e] = c;
+            }
+            *ch_ = vh; *cl_ = vl;
+        }
+        __syncthreads();
+    }
+    f16x8 kh[4], kl[4], qh[4], ql[4];
+    {
+        f32x4 acc[2][4];
+        project(wfh, wfl, p.bqkv, h * HD, acc);            // q_h: lane (lr, lg) holds d = {4 lg + r, 16 + 4 lg + r} of token 16 fi + lr
+        load_w(wq, E + h * HD, wfh, wfl);
+        pack(acc, qh, ql);
+        __builtin_amdgcn_sched_barrier(0);
+        project(wfh, wfl, p.bqkv, E + h * HD, acc);        // k_h: the same d set per lane -> a consistent contraction order for S^T
+        load_w(wq, 2 * E + h * HD, wfh, wfl);
+        pack(acc, kh, kl);
+        __builtin_amdgcn_sched_barrier(0);
+        project(wfh, wfl, p.bqkv, 2 * E + h * HD, acc);    // v_h -> V^T[d][token] (hi, lo) in LDS
+        if (p.wproj) load_w((const f16*)p.wproj, h * HD, wfh, wfl);   // projection weights: in flight during the whole attention
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f16 a, c;
+                    rs_split(acc[f][ft][r], a, c);
+                    vth[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = a;
+                    vtl[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = c;
+                }
+    }
+    __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tile (it is overwritten below)
+    f32x4 s[4][4];  // [fj][fi]
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[fj], ql[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[fj], qh[fi], c, 0, 0, 0);
+            const f32x4 m = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[fj], qh[fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[fj][fi][r] = fmaf(c[r], RS_LO_INV, m[r]);
+        }
+    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+    if (shift > 0) {   // region ids of the (quirky) shift mask: band of window_row*8 + token_column (see win_attn_kernel)
+        auto band = [&](int c) { const int yq = wy * WS + c; return yq < H - WS ? 0 : (yq < H - shift ? 1 : 2); };
+        rid_i = band(lr & 7);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
+    }
+    float inv[4];
+    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+        const int i = 16 * fi + lr;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                if (shift > 0 && rid_j[r] != rid_i) v += -100.0f;
+                s[fj][fi][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(s[fj][fi][r] - m);
+                s[fj][fi][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[fi] = 1.0f / l;
+    }
+    f32x4 om[2][4], oc[2][4];    // [fd][fi] main / cross
+#pragma unroll
+    for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) { om[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f16x8 vah[2], val[2], pbh[4], pbl[4];
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            const int o = (16 * fd + lr) * VP + 32 * ks + 4 * lg;
+            const f16x4 a0 = *(const f16x4*)(vth + o), a1 = *(const f16x4*)(vth + o + 16);
+            const f16x4 b0 = *(const f16x4*)(vtl + o), b1 = *(const f16x4*)(vtl + o + 16);
+            vah[fd] = f16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            val[fd] = f16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, bq;
+                rs_split(s[2 * ks][fi][r], a, bq);     pbh[fi][r] = a;     pbl[fi][r] = bq;
+                rs_split(s[2 * ks + 1][fi][r], a, bq); pbh[fi][4 + r] = a; pbl[fi][4 + r] = bq;
+            }
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                om[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[fd], pbh[fi], om[fd][fi], 0, 0, 0);
+                oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[fd], pbl[fi], oc[fd][fi], 0, 0, 0);
+                oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val[fd], pbh[fi], oc[fd][fi], 0, 0, 0);
+            }
+    }
+    f16* out = (f16*)p.out;
+    const long long ro = 2LL * p.ldo;   // output pixel record [ldo hi | ldo lo]
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fd = 0; fd < 2; ++fd) {
+            f16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, bq;
+                rs_split(fmaf(oc[fd][fi][r], RS_LO_INV, om[fd][fi][r]) * inv[fi], a, bq);
+                hv[r] = a; lv[r] = bq;
+            }
+            const int t = 16 * fi + lr, c = h * HD + 16 * fd + 4 * lg;     // token row, feature
+            if (!p.wproj) {
+                f16* dst = out + pixel(t) * ro + c;
+                *(f16x4*)dst = hv;
+                *(f16x4*)(dst + p.ldo) = lv;
+            } else {
+                // fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format)
+                char* cell = smem + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2;
+                *(f16x4*)cell = hv;
+                *(f16x4*)(cell + XS_PLANE) = lv;
+            }
+        }
+    if (!p.wproj) return;
+    // ---- fused output projection: wave h produces output features 32 h .. 32 h + 31 for all tokens, weights straight from L2
+    const f16* res = (const f16*)p.res;
+    const long long rr = 2LL * p.ldres;
+    long long pix[4];
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) pix[fi] = pixel(16 * fi + lr);
+    f16x4 rvh[2][4], rvl[2][4];
+    if (res) {   // shortcut: requested before the barrier, consumed after the projection
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const f16* rp = res + pix[fi] * rr + h * HD + 16 * f + 4 * lg;
+                rvh[f][fi] = *(const f16x4*)rp;
+                rvl[f][fi] = *(const f16x4*)(rp + p.ldres);
+            }
+    }
+    __syncthreads();   // all heads' attention results are in LDS
+    f32x4 acc2[2][4];
+    project(wfh, wfl, p.bproj, h * HD, acc2);
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16 a, c;
+                rs_split(acc2[f][fi][r] + (res ? rs_join(rvh[f][fi][r], rvl[f][fi][r]) : 0.f), a, c);
+                hv[r] = a; lv[r] = c;
+            }
+            f16* dst = out + pix[fi] * ro + h * HD + 16 * f + 4 * lg;
+            *(f16x4*)dst = hv;
+            *(f16x4*)(dst + p.ldo) = lv;
+        }
+}
+
+}  // namespace
+
+// fused qkv projection + window attention (+ output projection + shortcut) in split storage: 6 heads of 32; x / res / out are
+// split-storage NHWC tensors, wqkv / wproj split weight rows [K hi | K lo]
+extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t st) {
+    const WinAttnParams& p = *pp;
+    if ((p.H % 8) || (p.W % 8) || p.heads != 6 || (p.ldx % 8) || (p.ldo % 8) || !p.bias_n || !p.x || !p.wqkv || !p.bqkv) return -2;
+    if (p.shift != 0 && p.shift != 4) return -2;
+    if (p.wproj && (!p.bproj || (p.res && (p.ldres % 4)))) return -2;
+    const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 4;
+    if (xb >= 0xF0000000ull) return -2;
+    const int nwin = (p.H / 8) * (p.W / 8);
+    const size_t lds = (size_t)2 * 3 * 64 * 128 + (size_t)p.heads * 2 * 32 * (64 + 8) * sizeof(f16);
+    static bool attr_done[RS_MAX_DEVICES] = {};
+    bool& attr_set = attr_done[rs_device_slot()];
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -64,10 +64,10 @@ def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw
     return y
 
 
-def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None):
+def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=False):
     """Halo-tile 3x3 conv (igemm4.hip): x [B,H,W,Cin] raw tensor (fp16, or split storage as int32), coef [B,2,Cin] fp32 device
     (GroupNorm affine: scale row, shift row) applied with `act_in` (0 none / 2 SiLU) to x inside the kernel; returns [B,H,W,Cout]
-    in the same storage."""
+    in the same storage (with `want_stats` also the [B, max(1, H*W/256), Cout, 2] sums / sums of squares of the stored output)."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w_ref.shape[0]
@@ -75,10 +75,12 @@ def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None):
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=x.dtype)
     wh, wp = _hostf(w_ref)
     bh, bp = _hostf(bias) if bias is not None else (None, None)
+    st = torch.zeros(B, max(1, H * W // 256), Cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
     rc = lib.rs_op_conv3x3_halo(x.data_ptr(), coef.data_ptr() if coef is not None else None, act_in, wp, bp,
-                                res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout, prec, _lib.current_stream_ptr())
+                                res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout, prec,
+                                st.data_ptr() if st is not None else None, _lib.current_stream_ptr())
     _lib.check(rc, "rs_op_conv3x3_halo")
-    return y
+    return (y, st) if want_stats else y
 
 
 def gemm_nt(a, b, bias=None, scale=1.0, out_prec=None):
@@ -136,6 +138,26 @@ def window_attention_qkv(x, wqkv, bqkv, table, heads, shift, wproj=None, bproj=N
                                         bpd.data_ptr() if bpd is not None else None, res.data_ptr() if res is not None else None, out.data_ptr(),
                                         tp, B, H, W, heads, shift, _lib.current_stream_ptr())
     _lib.check(rc, "rs_op_window_attention_qkv")
+    return out
+
+
+def window_attention_qkv_split(x, wqkv, bqkv, table, heads, shift, wproj=None, bproj=None, res=None, xcoef=None):
+    """split storage: x [B,H,W,E] as int32 carrier ((hi, lo) fp16 pairs); weights any float dtype (packed to (hi, lo) rows here);
+    `xcoef` [B,2,E] fp32: GroupNorm affine applied to x on the fly.  Returns [B,H,W,E] split storage."""
+    lib = _lib.load()
+    B, H, W, E = x.shape
+    wd = split_pack_rows(wqkv).to(x.device)
+    bd = bqkv.to(x.device, torch.float32).contiguous()
+    wpd = split_pack_rows(wproj).to(x.device) if wproj is not None else None
+    bpd = bproj.to(x.device, torch.float32).contiguous() if bproj is not None else None
+    xc = xcoef.to(x.device, torch.float32).contiguous() if xcoef is not None else None
+    out = torch.empty(B, H, W, E, device=x.device, dtype=torch.int32)
+    th, tp = _hostf(table)
+    rc = lib.rs_op_window_attention_qkv_split(x.data_ptr(), wd.data_ptr(), bd.data_ptr(), wpd.data_ptr() if wpd is not None else None,
+                                              bpd.data_ptr() if bpd is not None else None, res.data_ptr() if res is not None else None,
+                                              out.data_ptr(), tp, xc.data_ptr() if xc is not None else None, B, H, W, heads, shift,
+                                              _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_window_attention_qkv_split")
     return out
 
 

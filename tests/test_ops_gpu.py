@@ -540,6 +540,37 @@ def test_window_attention_split(gpu, hw, shift):
     _close(_unsplit(out).permute(0, 3, 1, 2), ref, 5e-6, f"split window attention {hw} shift {shift}")
 
 
+@pytest.mark.parametrize("hw,shift,fold", [((16, 16), 0, False), ((16, 16), 4, True), ((8, 8), 0, True), ((24, 16), 4, False), ((64, 64), 4, True)])
+def test_window_attention_fused_qkv_split(gpu, hw, shift, fold):
+    """win_attn_qkv_split_kernel (win_attn_split.hip): GroupNorm affine + qkv Linear + W-MSA / SW-MSA + output projection + shortcut
+    in one launch on (hi, lo) fp16 pairs, against torch fp64 on the unrounded operands (fp32-class: nothing is rounded to fp16)."""
+    from resshift_amd import ops
+
+    H, W = hw
+    heads, E, B = 6, 192, 2
+    g = torch.Generator().manual_seed(H * 13 + shift)
+    x = torch.randn(B, E, H, W, generator=g)
+    wqkv = torch.randn(3 * E, E, generator=g) / math.sqrt(E)
+    bqkv = torch.randn(3 * E, generator=g) * 0.2
+    table = torch.randn(225, heads, generator=g) * 0.5
+    wproj = torch.randn(E, E, generator=g) / math.sqrt(E)
+    bproj = torch.randn(E, generator=g) * 0.2
+    res = torch.randn(B, E, H, W, generator=g)
+    coef = torch.stack([1.0 + 0.3 * torch.randn(B, E, generator=g), 0.2 * torch.randn(B, E, generator=g)], 1) if fold else None   # [B,2,E]
+    xn = x.double() * coef[:, 0, :, None, None].double() + coef[:, 1, :, None, None].double() if fold else x.double()
+    qkv = torch.einsum("bchw,oc->bohw", xn, wqkv.double()) + bqkv.double()[None, :, None, None]
+    attn = _window_attention_reference(qkv, table.double(), heads, shift)
+    # attention only
+    out = ops.window_attention_qkv_split(_split(x, gpu), wqkv, bqkv, table, heads, shift, xcoef=coef)
+    torch.cuda.synchronize()
+    _close(_unsplit(out).permute(0, 3, 1, 2), attn.float(), 5e-6, f"fused split qkv window attention {hw} shift {shift}")
+    # + output projection + shortcut
+    ref2 = torch.einsum("bchw,oc->bohw", attn, wproj.double()) + bproj.double()[None, :, None, None] + res.double()
+    out2 = ops.window_attention_qkv_split(_split(x, gpu), wqkv, bqkv, table, heads, shift, wproj=wproj, bproj=bproj, res=_split(res, gpu), xcoef=coef)
+    torch.cuda.synchronize()
+    _close(_unsplit(out2).permute(0, 3, 1, 2), ref2.float(), 5e-6, f"fused split qkv + proj window attention {hw} shift {shift}")
+
+
 def test_gemm_nt_batched_and_softmax_split(gpu):
     """AE mid-block attention in split storage: S = q k^T (fp32 out), softmax -> split P, o = P v + b"""
     from resshift_amd import ops
@@ -632,6 +663,89 @@ def test_conv3x3_halo_split_storage(gpu, case):
     y = ops.conv3x3_halo(_split(x, gpu), w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d)
     torch.cuda.synchronize()
     _close(_unsplit(y).permute(0, 3, 1, 2), ref, 3e-6, f"split halo conv {case}")
+
+
+# small planes of the 16 x 16 / 8 x 8 UNet levels on the halo kernel (igemm4_kernel.h, SEG > 0): four 8 x 8 images or one 16 x 16 image per
+# tile, split-K over the (chunk, tap) stage sequence with slices that start / end in the middle of a chunk, reduce kernel with the
+# GroupNorm statistics of the stored output.  (B, H, W, Cin, Cout, coef, res)
+SMALL_PLANE_CASES = [
+    (32, 8, 8, 640, 640, True, True),       # 8 tiles x 4 channel tiles, 8 slices of 22.5 (split) / 11.25 (fp16) stages
+    (32, 16, 16, 320, 320, True, True),     # 32 x 2 tiles, 4 slices
+    (32, 8, 8, 1280, 640, True, False),     # concat input, Cin = 20 (fp16) / 40 (split) chunks
+    (4, 8, 8, 320, 640, False, True),       # one tile per channel tile: 16 slices at most
+    (8, 16, 16, 960, 320, True, True),      # 15 chunks in fp16: the last one half full
+    (3, 16, 16, 160, 128, False, False),    # BC = 128, Cin = 2.5 fp16 chunks
+    (256, 8, 8, 320, 160, True, True),      # enough tiles without split-K? (64 x 1 tiles -> 4 slices)
+]
+
+
+def _stats_ref(y_nchw, slab):
+    """[B, C, H, W] -> [B, S, C, 2] sums / sums of squares over slabs of `slab` consecutive pixels"""
+    B, C, H, W = y_nchw.shape
+    v = y_nchw.reshape(B, C, -1)
+    S = max(1, (H * W) // slab)
+    v = v.reshape(B, C, S, -1).double()
+    return torch.stack([v.sum(-1), (v * v).sum(-1)], -1).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("case", SMALL_PLANE_CASES)
+def test_conv3x3_halo_small_planes(gpu, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, use_coef, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xd = _nhwc(x, torch.float16, gpu)
+    xr = _ref_in(xd)
+    coef_d = None
+    if use_coef:
+        a = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+        d = torch.randn(B, Cin, generator=g) * 0.5
+        coef_d = torch.stack([a, d], 1).contiguous().to(gpu)                       # [B, 2, Cin]: a DIFFERENT affine per image
+        xr = F.silu(xr * a[:, :, None, None] + d[:, :, None, None]).half().float()
+    ref = F.conv2d(xr, w.half().float(), bias, padding=1)
+    res_d = None
+    if use_res:
+        res_d = _nhwc(torch.randn(ref.shape, generator=g), torch.float16, gpu)
+        ref = ref + _ref_in(res_d)
+    y, st = ops.conv3x3_halo(xd, w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d, want_stats=True)
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), ref, TOL[torch.float16], f"halo conv, small planes {case}")
+    sref = _stats_ref(_ref_in(y), 256)     # statistics of the STORED fp16 values
+    err = ((st.cpu().double() - sref).abs() / (sref.abs() + 1.0)).max().item()
+    assert err < 1e-4, (case, err)
+
+
+@pytest.mark.parametrize("case", SMALL_PLANE_CASES)
+def test_conv3x3_halo_small_planes_split_storage(gpu, case):
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, use_coef, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31 + 1)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xr = x.double()
+    coef_d = None
+    if use_coef:
+        a = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+        d = torch.randn(B, Cin, generator=g) * 0.5
+        coef_d = torch.stack([a, d], 1).contiguous().to(gpu)
+        xr = F.silu(xr * a.double()[:, :, None, None] + d.double()[:, :, None, None])
+    ref = F.conv2d(xr, w.double(), bias.double(), padding=1)
+    res_d = None
+    if use_res:
+        r = torch.randn(ref.shape, generator=g)
+        res_d = _split(r, gpu)
+        ref = ref + r.double()
+    y, st = ops.conv3x3_halo(_split(x, gpu), w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d, want_stats=True)
+    torch.cuda.synchronize()
+    _close(_unsplit(y).permute(0, 3, 1, 2), ref, 3e-6, f"split halo conv, small planes {case}")
+    sref = _stats_ref(ref, 256)
+    err = ((st.cpu().double() - sref).abs() / (sref.abs() + 1.0)).max().item()
+    assert err < 1e-4, (case, err)
 
 
 @pytest.mark.parametrize("shape,pad", [((2, 3, 40, 28), (24, 20)), ((1, 1, 17, 64), (15, 0)), ((3, 3, 64, 64), (0, 0)), ((1, 3, 5, 7), (4, 6))])
