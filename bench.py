@@ -72,12 +72,19 @@ POLICIES = {
     "parity": dict(unet="split", encode="split", decode="fp16"),
 }
 PARITY_POLICY = "parity"
+# a cheaper mixture that still meets the criterion on the measured images (profiles/r2_precision_sweep_lastk.txt): the first
+# MIXED_FP16_STEPS sampling steps (t = T-1 ...) in fp16 - their error is damped by the posterior coefficients on the way to the final
+# latent - the remaining steps and the encoder in split precision, fp16 decoder.  Reported beside the all-split policy, never instead
+# of it: its margin is 0 - 2 flipped VQ codes per image instead of 0 - 1 per batch.
+MIXED_FP16_STEPS = 3
 
 
 def policy_args(name: str, steps: int):
     if name in POLICIES:
         p = POLICIES[name]
         return [p["unet"]] * steps, p["encode"], p["decode"]
+    if name == "parity_mixed":
+        return ["fp16" if t >= steps - MIXED_FP16_STEPS else "split" for t in range(steps)], "split", "fp16"
     if name.startswith("mixed"):
         # "mixed<k>": the last k timesteps (t = k-1 .. 0) in fp32, everything else fp16
         k = int(name[5:] or 1)
@@ -338,7 +345,15 @@ def main():
                 eng.profile_enable(False)
             parity.append(par)
             log(f"parity policy: {par}")
-        qualified = [p for p in parity if p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999]
+            # the cheaper mixture (first MIXED_FP16_STEPS steps fp16): its own entry, timed the same way
+            if steps > MIXED_FP16_STEPS + 1:
+                polm = policy_args("parity_mixed", steps)
+                parm = engine_parity(f"parity_mixed (first {MIXED_FP16_STEPS} steps fp16, then split; split encoder, fp16 decoder)", polm)
+                msm = timed(polm, args.steps)
+                parm.update({"ms_per_step": round(msm, 2), "images_per_sec": round(B / msm * 1e3, 2), "steps_timed": args.steps})
+                parity.append(parm)
+                log(f"mixed policy: {parm}")
+        qualified = [p for p in parity if p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999 and not p["policy"].startswith("parity_mixed")]
         if qualified:
             best = max(qualified, key=lambda p: p.get("images_per_sec", value))
             value_at_parity = {"value": best.get("images_per_sec", round(value, 3)), "unit": "images/sec", "policy": best["policy"],
@@ -402,6 +417,10 @@ def main():
                       "weight_broadcast_bytes": int(getattr(eng, "broadcast_bytes", 0)),
                       "weight_broadcast_ms": round(1e3 * float(getattr(eng, "broadcast_s", 0.0)), 3)},
             "value_at_parity": value_at_parity,
+            "value_at_parity_mixed": next(({"value": p["images_per_sec"], "unit": "images/sec", "policy": p["policy"], "image_psnr_db": p["image_psnr_db"],
+                                            "vq_code_agreement": p["vq_code_agreement"], "images": p["images"],
+                                            "meets_criterion": bool(p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999)}
+                                           for p in (parity or []) if p["policy"].startswith("parity_mixed")), None),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "torch_rocm_autocast_baseline": torch_baseline,
         }

@@ -215,7 +215,7 @@ struct Exec {
         const double M = (double)p.B * p.H * p.W;
         const int sp = dt == RS_F16S;
         igemm_flops[sp ? 2 : 0] += 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E;
-        fam_note(sp ? F_WINATTN_S : F_WINATTN, 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E + 2.0 * 2.0 * M * 64.0 * E);   // + QK^T and PV of the 64-token windows
+        fam_note(sp ? F_WINATTN_S : F_WINATTN, 2.0 * M * (p.wproj ? 4.0 : 3.0) * E * E + 2.0 * 2.0 * M * 64.0 * E, (long long)M, E, E);   // + QK^T and PV of the 64-token windows
         igemm_bytes += (sp ? 4.0 : 2.0) * (M * E * (p.res ? 3.0 : 2.0) + (p.wproj ? 4.0 : 3.0) * E * E);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -237,7 +237,7 @@ struct Exec {
                   int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0, int dt = RS_F16) {
         const int sp = dt == RS_F16S;
         igemm_flops[sp ? 2 : 0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
-        fam_note(sp ? F_SWINMLP_S : F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD);
+        fam_note(sp ? F_SWINMLP_S : F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD, M, E, HD);
         igemm_bytes += (sp ? 4.0 : 2.0) * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;

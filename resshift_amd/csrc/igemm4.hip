@@ -99,8 +99,11 @@ int reduce_stats_launch(const IGemmParams& p, int out_dt, hipStream_t st) {
 // (1: fp16 only, 2: split only); RS_IGEMM_V4_SEG=0 keeps the small planes on the generic kernels (A/B runs).
 extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC, int* SEG, int* SK) {
     static const int on = []() { const char* e = getenv("RS_IGEMM_V4"); return e ? atoi(e) : 3; }();
-    // bit 0: fp16, bit 1: split.  Default: split storage only - measured (profiles/r3_small_planes.txt): split 8 x 8 convs 96 -> 62 us,
-    // fp16 33 -> 39 us (the fp16 slices are 11 stages short: prologue, partial slab and reduce dominate; igemm2's 64-pixel tiles win)
+    // bit 0: fp16, bit 1: split storage, bit 2: the 16 x 16 planes as well.  Default 2 = the 8 x 8 planes in split storage - measured
+    // (profiles/r3_small_planes.txt, us per launch at batch 32, generic kernel -> halo kernel): split 8 x 8, 640 -> 640: 96 -> 62, 1280 ->
+    // 640: 179 -> 105; split 16 x 16, 320 -> 320: 56 -> 70; fp16 8 x 8: 33 -> 39; fp16 16 x 16: 37 -> 41 (fp16 slices are 11 stages short:
+    // prologue, partial slab and reduce dominate and igemm2's 64-pixel tiles win; the 16 x 16 planes already give the generic split
+    // kernel 256 tiles)
     static const int seg_on = []() { const char* e = getenv("RS_IGEMM_V4_SEG"); return e ? atoi(e) : 2; }();
     static const int min_tiles = []() { const char* e = getenv("RS_IGEMM_V4_MINTILES"); return e ? atoi(e) : 192; }();
     static const int sk_target = []() { const char* e = getenv("RS_IGEMM_V4_SKTARGET"); return e ? atoi(e) : 256; }();
@@ -114,7 +117,7 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
     int best = 128, bw = waste(128);
     if (waste(160) < bw) { best = 160; bw = waste(160); }
     int seg = 0;
-    if (p.Ho == 16 && p.Wo == 16) seg = 16;
+    if (p.Ho == 16 && p.Wo == 16 && (seg_on & 4)) seg = 16;
     else if (p.Ho == 8 && p.Wo == 8 && p.B % 4 == 0) seg = 8;
     if (seg && !((in_dt == RS_F16 && (seg_on & 1)) || (in_dt == RS_F16S && (seg_on & 2)))) seg = 0;
     if (seg) {

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // makes the compiler park the whole struct in scratch memory, and scratch loads inside the K loop drain the DMA queue)
     const float* const xcoef = p.xcoef;
     const int xact = p.xact, Hs = p.Hs, Ws = p.Ws;
+    const bool early_on = !(p.dbg & 16);   // A/B knob (RS_IG4_EARLY_GN=0): the GroupNorm pass as a phase of its own
     // halo row hr of the tile -> source pixel (image index in `img`); false: zero padding / separator column / outside the image
     auto halo_src = [&](int hr, unsigned& pix, int& img) -> bool {
         const int hy = hr / HWD, hx = hr - hy * HWD;
@@ -208,14 +209,22 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             if (halo_src((tid >> 2) + 128 * k, pix, img)) sp_in |= 1u << k;
         }
     }
-    auto apply_split = [&](int c, auto act_tag) {
+    constexpr int NCELL_S = (HROWS_P + 127) / 128;   // cell pairs per thread in the split-storage GroupNorm pass
+    // the 16 affine coefficients of a thread's channel group for chunk c (scale a, shift d)
+    struct Coef { f32x4 a0, a1, d0, d1; };
+    auto load_coef = [&](int c) -> Coef {
+        const float* sc = SPLIT ? xcoef + (long long)b * 2 * Cin + c * 32 + sp_cg * 8
+                                : xcoef + (long long)b * 2 * Cin + min(c * 64 + cg * 8, Cin - 8);   // (half chunks: upper cells are never multiplied)
+        return Coef{*(const f32x4*)sc, *(const f32x4*)(sc + 4), *(const f32x4*)(sc + Cin), *(const f32x4*)(sc + Cin + 4)};
+    };
+    auto apply_split = [&](int c, auto act_tag, Coef cf, auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_tag)::value;
+        constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
         const float* sc = xcoef + (long long)b * 2 * Cin + c * 32 + sp_cg * 8;
-        f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
-        f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        f32x4 a0 = cf.a0, a1 = cf.a1, d0 = cf.d0, d1 = cf.d1;
         char* xb = smem + (c & 1) * XBUF + (tid >> 2) * 128;
 #pragma unroll
-        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+        for (int k = K0; k < K1; ++k) {
             if (!((sp_in >> k) & 1)) continue;
             if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
                 const int hr = (tid >> 2) + 128 * k, hx = hr % HWD;
@@ -237,15 +246,15 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             *ch_ = vh; *cl_ = vl;
         }
     };
-    auto apply = [&](int c, auto act_tag) __attribute__((always_inline)) {   // (not inlined, its closure object lives in scratch memory)
+    auto apply = [&](int c, auto act_tag, Coef cf, auto k0_tag, auto k1_tag) __attribute__((always_inline)) {   // (not inlined, its closure object lives in scratch memory)
         constexpr int ACT = decltype(act_tag)::value;
+        constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
         const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
         const float* sc = xcoef + (long long)b * 2 * Cin + ch;
-        f32x4 a0 = *(const f32x4*)sc, a1 = *(const f32x4*)(sc + 4);
-        f32x4 d0 = *(const f32x4*)(sc + Cin), d1 = *(const f32x4*)(sc + Cin + 4);
+        f32x4 a0 = cf.a0, a1 = cf.a1, d0 = cf.d0, d1 = cf.d1;
         char* xb = smem + (c & 1) * XBUF + tid * 16;
 #pragma unroll
-        for (int k = 0; k < NCELL; ++k) {
+        for (int k = K0; k < K1; ++k) {
             if (!((cell_in >> k) & 1)) continue;
             if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
                 const int hr = (tid >> 3) + 64 * k, hx = hr % HWD;
@@ -263,6 +272,24 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         }
     };
 
+    // cells [K0, K1) of chunk c's halo buffer: GroupNorm affine (+FiLM) + activation, storage-specific
+    auto apply_cells = [&](int c, const Coef& cf, auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
+        if constexpr (SPLIT) {
+            if (xact == RS_ACT_SILU) apply_split(c, std::integral_constant<int, RS_ACT_SILU>{}, cf, k0_tag, k1_tag);
+            else apply_split(c, std::integral_constant<int, RS_ACT_NONE>{}, cf, k0_tag, k1_tag);
+        } else {
+            if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{}, cf, k0_tag, k1_tag);
+            else apply(c, std::integral_constant<int, RS_ACT_NONE>{}, cf, k0_tag, k1_tag);
+        }
+    };
+    constexpr int NC_ALL = SPLIT ? NCELL_S : NCELL, NC_HALF = (NC_ALL + 1) / 2;
+    // EARLY (RS_IG4_EARLY_GN=1; default OFF - measured neutral, profiles/r3_igemm4_early_gn.txt; not for the four-image tiles): the GroupNorm pass of chunk c + 1 does not get a phase of its
+    // own in front of that chunk's first stage - both waves of every SIMD in VALU code, the matrix pipe idle for 13 - 25 % of a chunk -
+    // but rides on the MFMAs of taps 7 and 8 of chunk c: the halo pieces of chunk c + 1 were requested with taps 0 .. 6 and are complete
+    // behind tap 7's barrier, half of a thread's cells go with each of the two stages, and the barrier that opens chunk c + 1 orders
+    // the LDS writes against the fragment reads.
+    constexpr bool EARLY = SEG != 8 && BC < 192 && !(ABL & 8);   // (BC = 192: the doubled stage body does not fit 256 VGPRs)
+    bool pre_applied = false;   // chunk c's halo was transformed during chunk c - 1
     const int nch = (Cin + KC - 1) / KC, nst = nch * 9;
     // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
     // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
@@ -304,19 +331,15 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                 if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (EARLY && tap == 0 && pre_applied) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's early GroupNorm writes
             __builtin_amdgcn_s_barrier();
             if (tap == t_first) {
-                if (xcoef) {
-                    if constexpr (SPLIT) {
-                        if (xact == RS_ACT_SILU) apply_split(c, std::integral_constant<int, RS_ACT_SILU>{});
-                        else apply_split(c, std::integral_constant<int, RS_ACT_NONE>{});
-                    } else {
-                        if (xact == RS_ACT_SILU) apply(c, std::integral_constant<int, RS_ACT_SILU>{});
-                        else apply(c, std::integral_constant<int, RS_ACT_NONE>{});
-                    }
+                if (xcoef && !pre_applied) {
+                    apply_cells(c, load_coef(c), std::integral_constant<int, 0>{}, std::integral_constant<int, NC_ALL>{});
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
+                pre_applied = false;
                 if (c > c_beg) {   // the fragment offsets move over to the other halo buffer
                     const int flip = (c & 1) ? XBUF : -XBUF;
 #pragma unroll
@@ -325,6 +348,10 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                         for (int q = 0; q < 3; ++q) xfo[j][q] += flip;
                 }
             }
+            // early GroupNorm pass of chunk c + 1 (see EARLY): possible when its halo pieces went out with taps 0 .. 6 of this chunk
+            const bool early = EARLY && xcoef != nullptr && c < c_last && t_first == 0 && early_on;
+            Coef cf_next{};
+            if (tap >= 7 && early) cf_next = load_coef(c + 1);   // (in front of this stage's refills: its wait does not drain them)
             // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
             // (a slice that enters the chunk at tap t_first > 0 has 9 - t_first stages for the XPW pieces: the rest goes with tap 8)
             if (c < c_last && !(ABL & 2)) {
@@ -337,46 +364,61 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
             const char* wb = smem + WBASE + (NSLOT == 3 ? tap % 3 : (s & 1)) * WSLOT + la;
             const int ky = tap / 3, kx = tap % 3;
-            if constexpr (SPLIT) {
-                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
-#pragma unroll
-                for (int j = 0; j < FP; ++j) {
-                    bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
-                    bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
-                }
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
-                    al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
-                }
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-            } else
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks == 1 && !two) break;
-                const int sw = ks ? swz1 : swz0;
-                f16x8 a[FC], bf[FP];
-#pragma unroll
-                for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
-#pragma unroll
-                for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
-#pragma unroll
-                for (int i = 0; i < FC; ++i)
+            // the stage's MFMAs (fragment reads of the nine shifted halo rows + the weight tile)
+            auto compute = [&]() __attribute__((always_inline)) {
+                if constexpr (SPLIT) {
+                    f16x8 ah[FC], al[FC], bh[FP], bl[FP];
 #pragma unroll
                     for (int j = 0; j < FP; ++j) {
-                        if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                        bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
+                        bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
                     }
-            }
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) {
+                        ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                        al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) {
+                        const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        if (ks == 1 && !two) break;
+                        const int sw = ks ? swz1 : swz0;
+                        f16x8 a[FC], bf[FP];
+#pragma unroll
+                        for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
+#pragma unroll
+                        for (int i = 0; i < FC; ++i)
+#pragma unroll
+                            for (int j = 0; j < FP; ++j) {
+                                if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                            }
+                    }
+                }
+            };
+            if (EARLY && tap >= 7 && early) {
+                // the two waves of a SIMD (w and w + 4: a workgroup's waves go to the SIMDs in cyclic order) take the two halves of
+                // the stage in opposite order: while one is in the GroupNorm VALU code the other keeps the matrix pipe busy
+                auto piece = [&]() __attribute__((always_inline)) {
+                    if (tap == 7) apply_cells(c + 1, cf_next, std::integral_constant<int, 0>{}, std::integral_constant<int, NC_HALF>{});
+                    else apply_cells(c + 1, cf_next, std::integral_constant<int, NC_HALF>{}, std::integral_constant<int, NC_ALL>{});
+                };
+                if (wave < 4) { piece(); __builtin_amdgcn_sched_barrier(0); compute(); }
+                else { compute(); __builtin_amdgcn_sched_barrier(0); piece(); }
+                if (tap == 8) pre_applied = true;
+            } else compute();
         }
     }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
@@ -597,6 +639,10 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    {   // A/B knob: RS_IG4_EARLY_GN=1 lets the GroupNorm pass of chunk c + 1 ride on taps 7 / 8 of chunk c
+        static const bool early = []() { const char* v = getenv("RS_IG4_EARLY_GN"); return v && v[0] == '1'; }();   // measured: no gain (profiles/r3_igemm4_early_gn.txt)
+        p.dbg = early ? 0 : 16;
+    }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if constexpr (!SPLIT && BC == 160 && SEG == 0) {
         static const int abl = []() { const char* v = getenv("RS_IGEMM4_ABL"); return v ? atoi(v) : 0; }();
