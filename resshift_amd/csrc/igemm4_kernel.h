@@ -288,7 +288,13 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // but rides on the MFMAs of taps 7 and 8 of chunk c: the halo pieces of chunk c + 1 were requested with taps 0 .. 6 and are complete
     // behind tap 7's barrier, half of a thread's cells go with each of the two stages, and the barrier that opens chunk c + 1 orders
     // the LDS writes against the fragment reads.
-    constexpr bool EARLY = SEG != 8 && BC < 192 && !(ABL & 8);   // (BC = 192: the doubled stage body does not fit 256 VGPRs)
+    // (compiled in only with -DRS_IG4_EARLY_BUILD: the doubled stage body costs registers - fp16 BC = 160: 185 -> 256 VGPRs; BC = 192
+    // does not fit at all)
+#ifdef RS_IG4_EARLY_BUILD
+    constexpr bool EARLY = SEG != 8 && BC < 192 && !(ABL & 8);
+#else
+    constexpr bool EARLY = false;
+#endif
     bool pre_applied = false;   // chunk c's halo was transformed during chunk c - 1
     const int nch = (Cin + KC - 1) / KC, nst = nch * 9;
     // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
@@ -300,19 +306,23 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
 #endif
     // split-K over stages: this workgroup's slice [s_beg, s_end) of the (chunk, tap) sequence (the whole sequence without split-K);
     // it may begin / end in the middle of a chunk.  (The planner leaves no slice empty.)
-    const int zsl = blockIdx.z;
+    // SLICED is a compile-time property (only the small-plane geometries are ever launched with split-K): without it the nine taps of a
+    // chunk stay ONE straight-line block - a per-tap range test costs the scheduler its view across the taps (measured: + 20 % on every
+    // big-plane shape, profiles/r3_igemm4_phases.txt)
+    constexpr bool SLICED = SEG != 0;
+    const int zsl = SLICED ? blockIdx.z : 0;
     int s_beg = 0, s_end = nst;
-    if (p.splitk > 1) {
+    if (SLICED && p.splitk > 1) {
         const int per = (nst + p.splitk - 1) / p.splitk;
         s_beg = min(nst, zsl * per);
         s_end = min(nst, s_beg + per);
     }
-    const int c_beg = s_beg / 9, c_last = (s_end - 1) / 9;
+    const int c_beg = SLICED ? s_beg / 9 : 0, c_last = SLICED ? (s_end - 1) / 9 : nch - 1;
 #pragma unroll
     for (int k = 0; k < XPW; ++k) issue_x(c_beg, k);
     issue_w(s_beg, NSLOT == 3 ? s_beg % 3 : (s_beg & 1));
     if (NSLOT == 3 && s_beg + 1 < s_end) issue_w(s_beg + 1, (s_beg + 1) % 3);
-    if (c_beg & 1) {   // the first chunk of the slice sits in halo buffer 1
+    if (SLICED && (c_beg & 1)) {   // the first chunk of the slice sits in halo buffer 1
 #pragma unroll
         for (int j = 0; j < FP; ++j)
 #pragma unroll
@@ -320,11 +330,11 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     }
     for (int c = c_beg; c <= c_last; ++c) {
         const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
-        const int t_first = c == c_beg ? s_beg - 9 * c_beg : 0;   // first tap of this chunk inside the slice
+        const int t_first = SLICED && c == c_beg ? s_beg - 9 * c_beg : 0;   // first tap of this chunk inside the slice
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = c * 9 + tap;
-            if (s < s_beg || s >= s_end) continue;   // (workgroup-uniform)
+            if constexpr (SLICED) { if (s < s_beg || s >= s_end) continue; }   // (workgroup-uniform)
             // weight tile s (and every halo piece issued before it) has landed: with three slots only the loads of tile s+1 - the
             // youngest RW (waves that also own a partial row group) or RWF ones of this wave - may still be in flight
             if (NSLOT == 3 && s + 1 < s_end) {
@@ -354,11 +364,15 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             if (tap >= 7 && early) cf_next = load_coef(c + 1);   // (in front of this stage's refills: its wait does not drain them)
             // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
             // (a slice that enters the chunk at tap t_first > 0 has 9 - t_first stages for the XPW pieces: the rest goes with tap 8)
-            if (c < c_last && !(ABL & 2)) {
-                const int k0 = tap - t_first;
-                if (k0 < XPW) issue_x(c + 1, k0);
-                if (tap == 8)
-                    for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
+            if constexpr (SLICED) {
+                if (c < c_last && !(ABL & 2)) {
+                    const int k0 = tap - t_first;
+                    if (k0 < XPW) issue_x(c + 1, k0);
+                    if (tap == 8)
+                        for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
+                }
+            } else {
+                if (c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
             }
             // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
             if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         if constexpr (SEG == 16) return ((long long)b * 16 + ty + 8 * (tx >> 4)) * 16 + (tx & 15);      // rows 8 .. 15 in segment 1
         return ((long long)b * p.Ho + y0 + ty) * p.Wo + x0 + tx;
     };
-    if (p.splitk > 1) {
+    if (SLICED && p.splitk > 1) {
         // split-K slice: raw fp32 partial sums (split storage: the accumulator carries 2^11 x the sum); scale / bias / activation /
         // residual / storage conversion are applied by the reduce kernel.  No LDS is touched: no barrier with the waves still looping.
         float* part = p.partial + (long long)zsl * p.M * p.Cout;
