@@ -250,12 +250,15 @@ def main():
         # scripts/collect_traffic.py into profiles/, because a process cannot attach rocprofv3 to itself.  The file is
         # stamped with the digest of the kernel sources it was measured on; a stale file is not reported.
         traffic = traffic_note = None
-        tpath = os.path.join(ROOT, "profiles", f"r2_pmc_traffic_igemm_{args.precision}.json")
+        tpath = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_{args.precision}.json")
+        gn_traffic = gn_trace_ms = None
         if args.config == "realsr" and B == 32 and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("kernel_source_digest") == kernel_source_digest():
                 traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)  # MB per launch
+                if tj.get("groupnorm", {}).get("launches_fetch_pass"):
+                    gn_traffic = round(tj["groupnorm"]["hbm_bytes_per_launch"] / 1e6, 3)
             else:
                 traffic_note = "profiles/ PMC file was collected on different kernel sources: not reported"
         roofline = {
@@ -271,15 +274,26 @@ def main():
         }
         # per kernel family (north_star: "per-kernel achieved-fraction-of-roofline"): same hipEvent brackets, grouped
         roofline["per_kernel"] = per_kernel_rooflines(eng)
+        # GroupNorm family time from the committed rocprofv3 kernel trace of this command (scripts/collect_gn_trace.py; digest-stamped):
+        # the hipEvent brackets cannot resolve 6 - 14 us kernels (their fixed cost is comparable to the kernels), the trace can
+        gpath = os.path.join(ROOT, "profiles", f"r3_gn_trace_{args.precision}.json")
+        if args.config == "realsr" and B == 32 and os.path.exists(gpath):
+            with open(gpath) as fh:
+                gj = json.load(fh)
+            if gj.get("kernel_source_digest") == kernel_source_digest():
+                gn_trace_ms = gj["ms_per_pass"]
         if st.get("gn_launches"):
-            gbs = st["gn_bytes"] / (st["gn_ms"] * 1e-3) / 1e9 if st["gn_ms"] > 0 else 0.0
+            gn_ms = gn_trace_ms if gn_trace_ms else st["gn_ms"]
+            gbs = st["gn_bytes"] / (gn_ms * 1e-3) / 1e9 if gn_ms > 0 else 0.0
             roofline["groupnorm"] = {
                 "bound": "hbm", "kernel": "gn_stats_kernel / gn_apply_kernel / gn_fused_kernel (GroupNorm32 + SiLU / FiLM)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_mb_per_launch": round(st["gn_bytes"] / st["gn_launches"] / 1e6, 3),
                 "note": "algorithmic bytes = every GroupNorm input read once + every output written once",
-                "launches_per_step": st["gn_launches"], "avg_launch_us": round(st["gn_ms"] * 1e3 / st["gn_launches"], 2),
-                "ms_per_step": round(st["gn_ms"], 2), "traffic": None,
+                "launches_per_step": st["gn_launches"], "avg_launch_us": round(gn_ms * 1e3 / st["gn_launches"], 2),
+                "ms_per_step": round(gn_ms, 2), "ms_per_step_source": "rocprofv3 kernel trace (profiles/)" if gn_trace_ms else "hipEvent brackets",
+                "ms_per_step_hipevents": round(st["gn_ms"], 2), "traffic": gn_traffic,
+                "traffic_unit": "MB of HBM traffic per kernel launch of the family (PMC)",
             }
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload; parity

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL call, see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libresshift_hip.so")
+LIB_PATH = os.environ.get("RESSHIFT_HIP_LIB") or os.path.join(HERE, "libresshift_hip.so")   # (override: A/B of two builds on one box)
 
 RS_PREC_F16 = 0
 RS_PREC_F32 = 1

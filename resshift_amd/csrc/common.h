@@ -56,6 +56,15 @@ template <> __device__ __forceinline__ void rs_st<h2s>(h2s* p, int lo, float v) 
 #define RS_MAX_DEVICES 64
 static inline int rs_device_slot() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < RS_MAX_DEVICES ? d : 0; }
 
+// Between a wave's writes to ITS OWN epilogue staging tile and its reads of that tile (and before the tile is overwritten) the wave's own
+// LDS instruction order is all that is needed: a workgroup barrier there makes every wave wait for the slowest one four times per
+// split-storage epilogue.  -DRS_EPI_FULL_BARRIER restores the barriers (A/B builds).
+#ifdef RS_EPI_FULL_BARRIER
+#define RS_STAGING_SYNC() __syncthreads()
+#else
+#define RS_STAGING_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float rs_silu(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (nn.GELU() default; reference models/swin_transformer.py:18)
@@ -235,4 +244,9 @@ struct WinAttnParams {
     const void* res;      // [B,H,W,ldres] fp16 shortcut, read at the same (un-shifted) pixels the result is written to
     int ldres;
     const float* xcoef;   // optional GroupNorm affine [B][2][E] (GNParams::coef): x is the raw tensor, normalised on the fly
+    // optional statistics of the stored output for the GroupNorm that consumes it (norm2, swin_transformer.py:279; GNParams::cpartial):
+    // [B][windows per image][ystats_ld][2] floats (sum, sum of squares over the window's 64 tokens), written by the fused kernels'
+    // projection epilogue (each wave owns 32 output features of ALL tokens of the window: a wave-local reduction, no atomics)
+    float* ystats;
+    int ystats_ld;
 };

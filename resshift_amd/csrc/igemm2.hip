@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * NWV, ((NS == 2 && BP == 128 && NWV == 8) || NW
         if (p.act == RS_ACT_GELU) finish(std::integral_constant<int, RS_ACT_GELU>{});
         else if (p.act == RS_ACT_SILU) finish(std::integral_constant<int, RS_ACT_SILU>{});
         else finish(std::integral_constant<int, RS_ACT_NONE>{});
-        __syncthreads();
+        RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         constexpr int CPR = (BC / 2) / 8;
         constexpr int NITEM = (BP / WPN) * CPR;
         const bool vec_ok = (p.ldy & 7) == 0;

@@ -551,14 +551,14 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                     for (int r = 0; r < 4; ++r) { f16 hh, ll; rs_split(acc[i][j][r], hh, ll); h[r] = half ? ll : hh; }
                     *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
                 }
-            __syncthreads();
+            RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
             for (int idx = lane; idx < NITEM; idx += 64) {
                 const int row = idx / CPR, c8 = idx - row * CPR;
                 const int n = n0 + wc * (BC / 2) + c8 * 8;
                 if (n >= p.Cout) continue;
                 *(uint4*)(y + pixel(row) * p.ldy * 2 + half * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
             }
-            __syncthreads();
+            RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         }
     } else {
         auto run = [&](auto res_tag) __attribute__((always_inline)) {
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         };
         if (res_ok) run(std::true_type{}); else run(std::false_type{});
         if (ystats) stats_out();
-        __syncthreads();
+        RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;
             const int n = n0 + wc * (BC / 2) + c8 * 8;

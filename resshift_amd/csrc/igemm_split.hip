@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
                 *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
                 *(f16x4*)(stg + WTILE + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = l;
             }
-        __syncthreads();
+        RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         constexpr int CPR = (BC / 2) / 8;
         constexpr int NITEM = (BP / WPN) * CPR;
         const bool vec_ok = (p.ldy & 7) == 0;

@@ -125,24 +125,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
     const int cpg = p.C / p.groups;
     // reduce the S partial sums of every group: 256/groups threads per group, then a fixed-order tree (deterministic)
     float* ps = gr + p.groups;         // [nsl][groups][2]
-    const int nsl = 256 / p.groups;
-    {
+    const int nsl = p.cpartial ? 1 : 256 / p.groups;
+    if (p.cpartial) {
+        // per-channel partials of the producing kernel's epilogue ([B][S][cp_ld][2]: halo conv tiles, split-K reduce slabs, attention
+        // windows, MLP wave tiles - up to 128 sets per image): thread = channel, consecutive threads read consecutive channels of one
+        // set (coalesced), S independent loads in flight per thread; then channels -> groups through LDS.  (One thread per (group,
+        // slice) walking cpg strided pairs per set made this launch as long as the statistics pass it replaces.)
+        float* chs = ca;               // [C][2] scratch in the coefficient arrays (2 * C floats, rewritten below)
+        for (int c = tid; c < p.C; c += 256) {
+            const float* in = p.cpartial + (((long long)b * p.S) * p.cp_ld + c) * 2;
+            float a = 0.f, q = 0.f;
+            for (int s2 = 0; s2 < p.S; ++s2) { const float2 v = *(const float2*)(in + (long long)s2 * p.cp_ld * 2); a += v.x; q += v.y; }
+            chs[2 * c] = a; chs[2 * c + 1] = q;
+        }
+        __syncthreads();
+        if (tid < p.groups) {
+            float a = 0.f, q = 0.f;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[2 * c]; q += chs[2 * c + 1]; }
+            ps[tid * 2] = a; ps[tid * 2 + 1] = q;
+        }
+    } else {
         const int g = tid % p.groups, sl = tid / p.groups;
         float a = 0.f, q = 0.f;
         if (sl < nsl) {
-            if (p.cpartial) {   // per-channel partials of the producing conv's epilogue: channels -> group on the fly
-                for (int s = sl; s < p.S; s += nsl) {
-                    const float* in = p.cpartial + (((long long)b * p.S + s) * p.cp_ld + g * cpg) * 2;
-                    for (int c = 0; c < cpg; ++c) { a += in[2 * c]; q += in[2 * c + 1]; }
-                }
-            } else {
-                for (int s = sl; s < p.S; s += nsl) {
-                    const float* in = p.partial + (((long long)b * p.S + s) * p.groups + g) * 2;
-                    a += in[0]; q += in[1];
-                }
+            for (int s = sl; s < p.S; s += nsl) {
+                const float* in = p.partial + (((long long)b * p.S + s) * p.groups + g) * 2;
+                a += in[0]; q += in[1];
             }
+            ps[(sl * p.groups + g) * 2] = a; ps[(sl * p.groups + g) * 2 + 1] = q;
         }
-        if (sl < nsl) { ps[(sl * p.groups + g) * 2] = a; ps[(sl * p.groups + g) * 2 + 1] = q; }
     }
     __syncthreads();
     if (tid < p.groups) {
@@ -982,15 +993,37 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         }
         f32x4 acc2[2][4];
         project(w, wf2, p.bproj, h * HD, acc2);
+        float s1[2][4], s2[2][4];   // per-channel sums of the STORED values over this lane's four tokens
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 f16x4 hv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
+                for (int r = 0; r < 4; ++r) {
+                    hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
+                    const float sv = (float)hv[r];
+                    s1[f][r] += sv; s2[f][r] = fmaf(sv, sv, s2[f][r]);
+                }
                 *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * f + 4 * lg) = hv;
             }
+        if (p.ystats) {   // statistics for norm2: the wave holds its 32 features of all 64 tokens of the window
+            const int wi = blockIdx.x * NW + w;
+            float* dst = p.ystats + (((long long)b * (nwx * (p.H / WS)) + wi) * p.ystats_ld + h * HD) * 2;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = s1[f][r], q = s2[f][r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                    if (lr == 0) { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
+                }
+        }
     }
 }
 

@@ -29,11 +29,33 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
 }
 
+// per-channel sum / sum of squares of a wave tile (32 tokens x 16 FC2 channels, lane (lr, lg) holds 4 channels of 2 tokens per channel
+// fragment) -> ystats[image][slab of 32 tokens][channel][2]; every token of the tile belongs to one image (HW % 32 == 0)
+template <int FC2>
+__device__ __forceinline__ void mlp_stats(const f32x4 (&o)[FC2][2], float* ystats, int ld, int mw, int HW, int c0, int lr, int lg) {
+    const int b = mw / HW, slab = (mw - b * HW) >> 5;
+    float* dst = ystats + (((long long)b * (HW >> 5) + slab) * ld + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < FC2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = o[i][0][r] + o[i][1][r], q = fmaf(o[i][0][r], o[i][0][r], o[i][1][r] * o[i][1][r]);
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) { a += __shfl_xor(a, sh); q += __shfl_xor(q, sh); }
+            if (lr == 0) { dst[(i * 16 + lg * 4 + r) * 2] = a; dst[(i * 16 + lg * 4 + r) * 2 + 1] = q; }
+        }
+}
+
 struct MlpParams {
     const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
     int M, ldx, ldres, ldy;
     const float* xcoef;   // optional GroupNorm affine [B][2][E] (GNParams::coef): x is the raw tensor, normalised while it is loaded
     int HW;               // tokens per image (a multiple of the 128-token tile whenever xcoef is set)
+    // optional statistics of the stored output for the GroupNorm that consumes it (the next block's norm1; GNParams::cpartial):
+    // [B][HW / 32][ystats_ld][2] floats = sum / sum of squares over the 32 tokens of one wave tile (wave-local, no atomics); needs
+    // HW % 32 == 0 and M % 32 == 0
+    float* ystats;
+    int ystats_ld;
 };
 
 template <int E, int HD>
@@ -203,9 +225,12 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
             f16x4 hv;
             hv[0] = (f16)v[0]; hv[1] = (f16)v[1]; hv[2] = (f16)v[2]; hv[3] = (f16)v[3];
             *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][j][r] = (float)hv[r];   // the stored value, for the statistics below
         }
     }
-    __syncthreads();
+    if (p.ystats && m0 + wp * 32 < p.M) mlp_stats<FC2>(o, p.ystats, p.ystats_ld, m0 + wp * 32, p.HW, wc * (E / 2), lr, lg);
+    RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
     constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
     for (int idx = lane; idx < NITEM; idx += 64) {
         const int row = idx / CPR, c8 = idx - row * CPR;
@@ -221,12 +246,14 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
 extern "C" int rs_swin_mlp_supported(int E, int HD) { return E == 192 && HD == 768; }
 
 extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
-                                  int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st) {
+                                  int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld,
+                                  hipStream_t st) {
+    if (ystats && (HW <= 0 || (HW & 31) || (M & 31))) return -2;
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
     if (xcoef && (HW <= 0 || HW % 128)) return -2;
     MlpParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
-    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW; p.ystats = ystats; p.ystats_ld = ystats_ld;
     constexpr int LDS = 160 * 1024;
     static bool attr_done[RS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[rs_device_slot()];
@@ -262,6 +289,8 @@ struct MlpSplitParams {
     int M, ldx, ldres, ldy;
     const float* xcoef;   // optional GroupNorm affine [B][2][E]: x is the raw tensor, normalised (joined value) while it is loaded
     int HW;
+    float* ystats;        // optional output statistics, as MlpParams::ystats
+    int ystats_ld;
 };
 
 template <int E, int HD>
@@ -424,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
             o[i][j] = v;
         }
     }
+    if (p.ystats && m0 + wp * 32 < p.M) mlp_stats<FC2>(o, p.ystats, p.ystats_ld, m0 + wp * 32, p.HW, wc * (E / 2), lr, lg);
     constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -436,14 +466,14 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
                 for (int r = 0; r < 4; ++r) { f16 hh, ll; rs_split(o[i][j][r], hh, ll); h[r] = half ? ll : hh; }
                 *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
             }
-        __syncthreads();
+        RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;
             const int m = m0 + wp * 32 + row;
             if (m >= p.M) continue;
             *(uint4*)(p.y + (long long)m * p.ldy * 2 + half * p.ldy + wc * (E / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
-        __syncthreads();
+        RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
     }
 }
 
@@ -451,12 +481,14 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
 
 // split storage: x / res / y tensors of (hi, lo) pairs, w1 / w2 packed [rows][K hi | K lo]
 extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
-                                        int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, hipStream_t st) {
+                                        int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld,
+                                        hipStream_t st) {
+    if (ystats && (HW <= 0 || (HW & 31) || (M & 31))) return -2;
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
     if (xcoef && (HW <= 0 || HW % 128)) return -2;
     MlpSplitParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
-    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW;
+    p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW; p.ystats = ystats; p.ystats_ld = ystats_ld;
     constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
     static bool attr_done[RS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[rs_device_slot()];

@@ -301,6 +301,11 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     __syncthreads();   // all heads' attention results are in LDS
     f32x4 acc2[2][4];
     project(wfh, wfl, p.bproj, h * HD, acc2);
+    float s1[2][4], s2[2][4];   // per-channel sums of the stored values (the pair reproduces v to 2^-23) over this lane's four tokens
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -309,13 +314,27 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f16 a, c;
-                rs_split(acc2[f][fi][r] + (res ? rs_join(rvh[f][fi][r], rvl[f][fi][r]) : 0.f), a, c);
+                const float v = acc2[f][fi][r] + (res ? rs_join(rvh[f][fi][r], rvl[f][fi][r]) : 0.f);
+                rs_split(v, a, c);
                 hv[r] = a; lv[r] = c;
+                s1[f][r] += v; s2[f][r] = fmaf(v, v, s2[f][r]);
             }
             f16* dst = out + pix[fi] * ro + h * HD + 16 * f + 4 * lg;
             *(f16x4*)dst = hv;
             *(f16x4*)(dst + p.ldo) = lv;
         }
+    if (p.ystats) {   // statistics for norm2: the wave holds its 32 features of all 64 tokens of the window
+        float* dst = p.ystats + (((long long)b * (nwx * (H / WS)) + blockIdx.x) * p.ystats_ld + h * HD) * 2;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[f][r], q = s2[f][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                if (lr == 0) { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
+            }
+    }
 }
 
 }  // namespace

@@ -8,10 +8,10 @@ import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from resshift_amd import build as _b  # kernel-source digest: bench.py ignores the file when the sources have changed since
 
-def total(path, counter):
+def total(path, counter, keys=("igemm", "swin_mlp", "win_attn_qkv")):
     s = 0.0; n = 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("igemm", "swin_mlp", "win_attn_qkv")):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in keys):
             s += float(r["Counter_Value"]); n += 1
     return s, n
 
@@ -21,6 +21,13 @@ out = {"kernel_family": "igemm*_kernel + swin_mlp_kernel + win_attn_qkv_kernel",
        "fetch_bytes_per_launch": 2.0 * f * 1024 / max(1, nf), "write_bytes_per_launch": w * 1024 / max(1, nw),
        "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units, separate --pmc passes"}
 out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+# the HBM-bound GroupNorm family (gn_stats / gn_apply / gn_fused kernels), same passes, same corrections
+GN = ("gn_stats_kernel", "gn_apply_kernel", "gn_fused_kernel")
+gf, gnf = total(sys.argv[1], "FETCH_SIZE", GN)
+gw, gnw = total(sys.argv[2], "WRITE_SIZE", GN)
+out["groupnorm"] = {"kernel_family": " / ".join(GN), "launches_fetch_pass": gnf, "launches_write_pass": gnw,
+                    "fetch_bytes_per_launch": 2.0 * gf * 1024 / max(1, gnf), "write_bytes_per_launch": gw * 1024 / max(1, gnw)}
+out["groupnorm"]["hbm_bytes_per_launch"] = out["groupnorm"]["fetch_bytes_per_launch"] + out["groupnorm"]["write_bytes_per_launch"]
 out["kernel_source_digest"] = _b._digest()[:16]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
