@@ -187,11 +187,14 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
 /* halo-tile 3x3 conv with the GroupNorm affine + activation of its input fused in (igemm4.hip): y = conv3x3(act_in(x * coef[b][0][c]
  * + coef[b][1][c])) (+res); x / res / y NHWC device tensors in `prec` storage (RS_PREC_F16 or RS_PREC_SPLIT), coef_dev [B][2][Cin]
  * fp32 device (null: plain conv), act_in 0 / 2 (none / SiLU), weights [Cout][Cin][3][3] fp32 host.  `ystats_dev` (may be null):
- * [B][max(1, H*W/256)][Cout][2] fp32 device, receives the per-(image, 256-pixel slab, channel) sum / sum of squares of the stored
+ * [B][H*W / rs_op_conv3x3_halo_stats_px(...)][Cout][2] fp32 device, receives the per-(image, 256-pixel slab, channel) sum / sum of squares of the stored
  * output (the GroupNorm statistics the kernel - or, for its split-K launches on the 16x16 / 8x8 planes, the reduce kernel - leaves
  * for the consuming GroupNorm).  Returns an error when the shape is not eligible for that kernel. */
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res,
                        void* y, int B, int H, int W, int Cin, int Cout, int prec, float* ystats_dev, void* stream);
+/* pixels per statistics slab rs_op_conv3x3_halo uses for this shape (0: shape not eligible / no statistics): ystats_dev is
+ * [B][H*W / slab][Cout][2] (256- or 128-pixel tiles of the kernel variant, or the reduce kernel's slabs for its split-K launches) */
+int rs_op_conv3x3_halo_stats_px(int B, int H, int W, int Cin, int Cout, int prec);
 /* batched NT GEMM: y[z][m][n] = scale * sum_k a[z][m][k] * b[z][n][k]  (+bias[n]) */
 int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale,
                   int in_prec, int out_prec, void* stream);

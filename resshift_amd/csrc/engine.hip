@@ -36,6 +36,7 @@ int rs_igemm_launch(const IGemmParams* p, int in_dt, int out_dt, int nz, hipStre
 int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt);
 int rs_igemm4_pick(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC);
 int rs_igemm4_plan(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC, int* SEG, int* SK);
+int rs_igemm4_stats_px(const IGemmParams* p, int in_dt);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_groupnorm_launch(const GNParams* p, int dt, int apply_slabs, hipStream_t st);
 int rs_win_attn_launch(const WinAttnParams* p, int dt, hipStream_t st);
@@ -699,12 +700,13 @@ struct rs_engine {
     void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res) {
         static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
         const int HW = y.H * y.W;
-        int sk = 1, seg = 0;
-        if (!on || ex.trace || !halo_conv(w, x, y, res, &sk, &seg)) return;
-        // tile epilogue: 256-pixel tiles of one image; split-K launches: the reduce kernel, in slabs of 256 pixels (or the whole
-        // image when it is smaller: the 8 x 8 planes)
-        if (sk > 1 ? (HW > 256 && (HW % 256)) : ((HW % 256) || seg == 8)) return;
-        y.stS = std::max(1, HW / 256); y.stld = y.ld;
+        if (!on || ex.trace || !halo_conv(w, x, y, res)) return;
+        // one partial set per pixel tile of the kernel variant (256 or 128 pixels of one image); split-K launches: the reduce kernel,
+        // in slabs of 256 pixels (or the whole image when it is smaller: the 8 x 8 planes)
+        const IGemmParams pp = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
+        const int spx = rs_igemm4_stats_px(&pp, x.dt);
+        if (spx <= 0 || (HW % spx)) return;
+        y.stS = HW / spx; y.stld = y.ld;
         y.st = (float*)ex.raw((size_t)y.B * y.stS * y.stld * 2 * sizeof(float));
     }
     // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
@@ -1693,6 +1695,15 @@ int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const f
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);
     return rc;
+}
+
+// pixels per statistics slab that rs_op_conv3x3_halo would use for this shape (0: not eligible / no statistics): the caller sizes ystats_dev
+// as [B][H*W / slab][Cout][2]
+int rs_op_conv3x3_halo_stats_px(int B, int H, int W, int Cin, int Cout, int prec) {
+    IGemmParams p{};
+    p.C0 = Cin; p.ld0 = Cin; p.B = B; p.Hs = H; p.Ws = W; p.up = 1; p.Ho = H; p.Wo = W;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = 9 * Cin;
+    return rs_igemm4_stats_px(&p, prec);
 }
 
 int rs_op_gemm_nt(const void* a, const void* b, const float* bias_dev, void* y, int nz, int M, int N, int K, float scale, int in_prec,

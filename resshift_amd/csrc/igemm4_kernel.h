@@ -64,26 +64,36 @@ __device__ long long g_ig4_clk[4 * 8192];   // per workgroup: cycle counter at k
 #endif
 // ABL (builds with -DRS_SPLIT_ABLATE only, RS_IGEMM4_ABL=n selects): timing ablations, results wrong: bit 0 = no weight loads
 // after the first two stages, bit 1 = no halo loads after chunk 0, bit 2 = no MFMAs
-template <int TW, int BC, bool SPLIT, int SEG = 0, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
-    static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16)), "segmented tiles use the 8 x 32 geometry");
+// NWV = 4 (igemm4w.hip): 128-pixel tiles (4 x 32) on FOUR waves (2 pixel-waves x 2 channel-waves, the same 64 x BC/2 wave tile) with ONE halo
+// buffer and two (BC = 128: three) weight slots: <= 80 KB of LDS, so TWO workgroups share a CU.  A single workgroup of this shape is
+// slower than the 8-wave one (the next chunk's halo can only be requested once the current one has been read to the end: one exposed L2
+// round trip per chunk), but the other workgroup's MFMAs fill that gap, and - the point - its K loop runs while this one sits in its
+// prologue or in its HBM-bound epilogue (15 - 23 % of a split-storage tile, profiles/r3_igemm4_phases.txt).
+template <int TW, int BC, bool SPLIT, int SEG = 0, int ABL = 0, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
+    static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16) && NWV == 8), "segmented tiles use the 8 x 32 geometry");
+    static_assert(NWV == 8 || NWV == 4, "8 waves (one workgroup per CU) or 4 waves (two per CU)");
+    constexpr int NT = 64 * NWV, WPX = NWV / 2;   // threads; pixel-waves (x 2 channel-waves)
+    constexpr int NXB = NWV == 8 ? 2 : 1;         // halo buffers
+    constexpr int LDSCAP = NWV == 8 ? 160 * 1024 : 80 * 1024;
     constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
     // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
     // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
-    constexpr int TH = 256 / TW, HWD = (TW + 2 + 7) / 8 * 8, HROWS = (TH + 2) * HWD, HROWS_P = HROWS;
+    constexpr int TH = 32 * NWV / TW, HWD = (TW + 2 + 7) / 8 * 8, HROWS = (TH + 2) * HWD, HROWS_P = HROWS;
     constexpr int XBUF = HROWS_P * 128;
     constexpr int WSLOT = BC * 128;
-    constexpr int WBASE = 2 * XBUF;
+    constexpr int WBASE = NXB * XBUF;
     // weight ring: three slots wherever 160 KB allow it (tile s+2 is requested at stage s and has two stages to land: with two
     // slots the L2 round trip of tile s+1 - ~1 us under load against a 1.1 us stage - shows up as 8 - 14 % of the kernel time,
     // profiles/r2_igemm4_ablation.txt); (TW = 64, BC = 160) and BC = 192 keep two
-    constexpr int NSLOT = (2 * XBUF + 3 * WSLOT <= 160 * 1024) ? 3 : 2;
+    constexpr int NSLOT = (NXB * XBUF + 3 * WSLOT <= LDSCAP) ? 3 : 2;
     constexpr int FP = 4, FC = BC / 32;
     constexpr int XPIECES = HROWS_P / 8;        // 1 KB LDS-DMA pieces (8 halo rows x 128 B) of one chunk
-    constexpr int XPW = (XPIECES + 7) / 8;      // pieces per wave (wave w owns pieces w, w+8, ...)
-    constexpr int RWF = BC / 64, RWP = BC % 64, RW = RWF + (RWP ? 1 : 0);
-    constexpr int NCELL = (HROWS_P * 8 + 511) / 512;   // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
-    static_assert(XPW <= 8 && RWP % 8 == 0 && 2 * XBUF + NSLOT * WSLOT <= 160 * 1024, "tile");
+    constexpr int XPW = (XPIECES + NWV - 1) / NWV;      // pieces per wave (wave w owns pieces w, w + NWV, ...)
+    constexpr int RR = 8 * NWV;                         // weight rows covered by one LDS-DMA instruction of every wave
+    constexpr int RWF = BC / RR, RWP = BC % RR, RW = RWF + (RWP ? 1 : 0);
+    constexpr int NCELL = (HROWS_P * 8 + NT - 1) / NT;  // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
+    static_assert(XPW <= 8 && RWP % 8 == 0 && NXB * XBUF + NSLOT * WSLOT <= LDSCAP, "tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int wp = wave & 3, wc = wave >> 2;
+    const int wp = wave % WPX, wc = wave / WPX;
     const int rr = 8 * wave + (lane >> 3);
     const int kcp = (lane & 7) ^ ((lane >> 3) & 7);    // source K-chunk of this lane (swizzle on the source side)
     const bool wpart = !RWP || wave < RWP / 8;
@@ -139,9 +149,9 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // the K loop they push the kernel over 256 VGPRs, and a spilled value comes back through a scratch load - a VMEM access whose
     // wait also drains the DMA queue.
     const int Cout = p.Cout, Ktot = p.Ktot, ld0 = p.ld0;
-    auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w+8, ...)
-        if (wave + 8 * k >= XPIECES) return;                       // wave-uniform
-        const int hr = 8 * (wave + 8 * k) + (lane >> 3);
+    auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w + NWV, ...)
+        if (wave + NWV * k >= XPIECES) return;                       // wave-uniform
+        const int hr = 8 * (wave + NWV * k) + (lane >> 3);
         unsigned pix; int img;
         const bool inside = halo_src(hr, pix, img);
         // source of LDS position (lane & 7) of this row = logical chunk kcp: fp16: channels 8 kcp ..; split: plane kcp >> 2
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
         const bool ok = inside && cb < (unsigned)Cin;
         const unsigned off = SPLIT ? pix * (unsigned)ld0 * 4u + (kcp >> 2) * (unsigned)ld0 * 2u + cb * 2u : pix * (unsigned)ld0 * 2u + cb * 2u;
-        lds_dma16(rx, smem + (c & 1) * XBUF + (wave + 8 * k) * 1024, ok ? off : INV);
+        lds_dma16(rx, smem + (NXB == 2 ? (c & 1) * XBUF : 0) + (wave + NWV * k) * 1024, ok ? off : INV);
     };
     auto issue_w = [&](int s, int slot) {   // weight tile of stage s = (chunk s / 9, tap s % 9) -> ring slot s % NSLOT (passed in)
         const int c = s / 9, tap = s - c * 9;
@@ -160,9 +170,9 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             if (RWP && i == RW - 1 && !wpart) continue;
-            const int n = n0 + 64 * i + rr;
-            const bool ok = 64 * i + rr < BC && n < Cout && cb < (unsigned)Cin;
-            lds_dma16(rw, sbase + (64 * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + kb : INV);
+            const int n = n0 + RR * i + rr;
+            const bool ok = RR * i + rr < BC && n < Cout && cb < (unsigned)Cin;
+            lds_dma16(rw, sbase + (RR * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + kb : INV);
         }
     };
 
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
 #pragma unroll
     for (int k = 0; k < NCELL; ++k) {
         unsigned pix; int img;
-        if (halo_src((tid >> 3) + 64 * k, pix, img)) cell_in |= 1u << k;
+        if (halo_src((tid >> 3) + (NT / 8) * k, pix, img)) cell_in |= 1u << k;
     }
     // split storage: thread t owns, in rows (t >> 2) + 128 k, the position pair (t & 3, (t & 3) + 4) = the hi and the lo half (in
     // swizzle-dependent order) of ONE 8-channel group
@@ -204,12 +214,12 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     unsigned sp_in = 0;
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int k = 0; k < (HROWS_P + 127) / 128; ++k) {
+        for (int k = 0; k < (HROWS_P + NT / 4 - 1) / (NT / 4); ++k) {
             unsigned pix; int img;
-            if (halo_src((tid >> 2) + 128 * k, pix, img)) sp_in |= 1u << k;
+            if (halo_src((tid >> 2) + (NT / 4) * k, pix, img)) sp_in |= 1u << k;
         }
     }
-    constexpr int NCELL_S = (HROWS_P + 127) / 128;   // cell pairs per thread in the split-storage GroupNorm pass
+    constexpr int NCELL_S = (HROWS_P + NT / 4 - 1) / (NT / 4);   // cell pairs per thread in the split-storage GroupNorm pass
     // the 16 affine coefficients of a thread's channel group for chunk c (scale a, shift d)
     struct Coef { f32x4 a0, a1, d0, d1; };
     auto load_coef = [&](int c) -> Coef {
@@ -222,17 +232,17 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
         const float* sc = xcoef + (long long)b * 2 * Cin + c * 32 + sp_cg * 8;
         f32x4 a0 = cf.a0, a1 = cf.a1, d0 = cf.d0, d1 = cf.d1;
-        char* xb = smem + (c & 1) * XBUF + (tid >> 2) * 128;
+        char* xb = smem + (NXB == 2 ? (c & 1) * XBUF : 0) + (tid >> 2) * 128;
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             if (!((sp_in >> k) & 1)) continue;
             if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
-                const int hr = (tid >> 2) + 128 * k, hx = hr % HWD;
+                const int hr = (tid >> 2) + (NT / 4) * k, hx = hr % HWD;
                 const float* si = sc + (long long)((hx - 1) / (SEG + 1)) * 2 * Cin;
                 a0 = *(const f32x4*)si; a1 = *(const f32x4*)(si + 4); d0 = *(const f32x4*)(si + Cin); d1 = *(const f32x4*)(si + Cin + 4);
             }
-            f16x8* ch_ = (f16x8*)(xb + k * 16384 + sp_hi * 16);
-            f16x8* cl_ = (f16x8*)(xb + k * 16384 + (sp_hi ^ 4) * 16);
+            f16x8* ch_ = (f16x8*)(xb + k * (NT / 4) * 128 + sp_hi * 16);
+            f16x8* cl_ = (f16x8*)(xb + k * (NT / 4) * 128 + (sp_hi ^ 4) * 16);
             f16x8 vh = *ch_, vl = *cl_;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -252,16 +262,16 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
         const int ch = min(c * 64 + cg * 8, Cin - 8);   // (half chunks: the upper cells are never multiplied; keep the loads in range)
         const float* sc = xcoef + (long long)b * 2 * Cin + ch;
         f32x4 a0 = cf.a0, a1 = cf.a1, d0 = cf.d0, d1 = cf.d1;
-        char* xb = smem + (c & 1) * XBUF + tid * 16;
+        char* xb = smem + (NXB == 2 ? (c & 1) * XBUF : 0) + tid * 16;
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             if (!((cell_in >> k) & 1)) continue;
             if constexpr (SEG == 8) {   // four images in the tile: the cell's own image's coefficients (L1-resident)
-                const int hr = (tid >> 3) + 64 * k, hx = hr % HWD;
+                const int hr = (tid >> 3) + (NT / 8) * k, hx = hr % HWD;
                 const float* si = sc + (long long)((hx - 1) / (SEG + 1)) * 2 * Cin;
                 a0 = *(const f32x4*)si; a1 = *(const f32x4*)(si + 4); d0 = *(const f32x4*)(si + Cin); d1 = *(const f32x4*)(si + Cin + 4);
             }
-            f16x8* cell = (f16x8*)(xb + k * 8192);
+            f16x8* cell = (f16x8*)(xb + k * NT * 16);
             f16x8 v = *cell;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // (compiled in only with -DRS_IG4_EARLY_BUILD: the doubled stage body costs registers - fp16 BC = 160: 185 -> 256 VGPRs; BC = 192
     // does not fit at all)
 #ifdef RS_IG4_EARLY_BUILD
-    constexpr bool EARLY = SEG != 8 && BC < 192 && !(ABL & 8);
+    constexpr bool EARLY = SEG != 8 && BC < 192 && NXB == 2 && !(ABL & 8);
 #else
     constexpr bool EARLY = false;
 #endif
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     for (int k = 0; k < XPW; ++k) issue_x(c_beg, k);
     issue_w(s_beg, NSLOT == 3 ? s_beg % 3 : (s_beg & 1));
     if (NSLOT == 3 && s_beg + 1 < s_end) issue_w(s_beg + 1, (s_beg + 1) % 3);
-    if (SLICED && (c_beg & 1)) {   // the first chunk of the slice sits in halo buffer 1
+    if (SLICED && NXB == 2 && (c_beg & 1)) {   // the first chunk of the slice sits in halo buffer 1
 #pragma unroll
         for (int j = 0; j < FP; ++j)
 #pragma unroll
@@ -344,13 +354,21 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             if (EARLY && tap == 0 && pre_applied) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's early GroupNorm writes
             __builtin_amdgcn_s_barrier();
             if (tap == t_first) {
+                if (NXB == 1 && c > c_beg) {
+                    // single halo buffer: every wave is behind chunk c - 1's last fragment reads (this stage's barrier), so chunk c is
+                    // requested only now - one exposed L2 round trip per chunk, covered by the other workgroup on this CU
+#pragma unroll
+                    for (int k = 0; k < XPW; ++k) issue_x(c, k);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
                 if (xcoef && !pre_applied) {
                     apply_cells(c, load_coef(c), std::integral_constant<int, 0>{}, std::integral_constant<int, NC_ALL>{});
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
                 pre_applied = false;
-                if (c > c_beg) {   // the fragment offsets move over to the other halo buffer
+                if (NXB == 2 && c > c_beg) {   // the fragment offsets move over to the other halo buffer
                     const int flip = (c & 1) ? XBUF : -XBUF;
 #pragma unroll
                     for (int j = 0; j < FP; ++j)
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
                         for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
                 }
             } else {
-                if (c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
+                if (NXB == 2 && c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
             }
             // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
             if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
     // 4 channels of every channel fragment over its FP pixel fragments, then the 16 `lr` lanes are reduced with xor-shuffles
     float* const ystats = p.ystats;
     // (LDS: the staging tiles end below 8 * 64 * ROWB <= 106 KB; the partials sit behind them)
-    float* const sb = (float*)(smem + 8 * 64 * ROWB);
+    float* const sb = (float*)(smem + NWV * 64 * ROWB);
     // wave-level sum of one (channel fragment, register) column over the 16 pixel lanes -> LDS
     auto stats_put = [&](int i, int r, float a, float q) {
 #pragma unroll
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void igemm4_kernel(IGemmParams p) {
             const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
             float a = 0.f, q = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (BC / 2) + cl) * 2 + 1]; }
+            for (int w4 = 0; w4 < WPX; ++w4) { a += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2 + 1]; }
             // (SEG = 16: the tile IS the image; SEG = 8 never produces statistics here - four images per tile)
             float* dst = ystats + ((SEG ? (long long)b : (long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + tid) * 2;
             dst[0] = a; dst[1] = q;
@@ -635,17 +653,18 @@ extern "C" int rs_igemm4_phase_cycles(int nwg, double* out3) {
 namespace {
 #endif
 
-template <int TW, int BC, bool SPLIT, int SEG = 0>
+template <int TW, int BC, bool SPLIT, int SEG = 0, int NWV = 8>
 hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
-    constexpr int TH = 256 / TW;
+    constexpr int TH = 32 * NWV / TW, NXB = NWV == 8 ? 2 : 1;
+    constexpr size_t cap = NWV == 8 ? 160 * 1024 : 80 * 1024;
     constexpr size_t xbuf = (size_t)((TH + 2) * ((TW + 2 + 7) / 8 * 8)) * 128;
-    constexpr size_t lds = 2 * xbuf + ((2 * xbuf + 3 * BC * 128 <= 160 * 1024) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
+    constexpr size_t lds = NXB * xbuf + ((NXB * xbuf + 3 * BC * 128 <= cap) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
     const int tiles = (SEG == 8 ? p.B / 4 : SEG == 16 ? p.B : p.B * (p.Ho / TH) * (p.Wo / TW)) * ((p.Cout + BC - 1) / BC);
     const int sk = p.splitk > 1 ? p.splitk : 1;
     static bool attr_done[RS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[rs_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const size_t esz = SPLIT ? 4 : 2;
@@ -658,7 +677,7 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
         p.dbg = early ? 0 : 16;
     }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
-    if constexpr (!SPLIT && BC == 160 && SEG == 0) {
+    if constexpr (!SPLIT && BC == 160 && SEG == 0 && NWV == 8) {
         static const int abl = []() { const char* v = getenv("RS_IGEMM4_ABL"); return v ? atoi(v) : 0; }();
 #define RS_ABL4_CASE(A)                                                                                                              \
     if (abl == A) {                                                                                                                    \
@@ -670,7 +689,7 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
 #undef RS_ABL4_CASE
     }
 #endif
-    hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG>), dim3(tiles, 1, sk), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>), dim3(tiles, 1, sk), dim3(64 * NWV), lds, st, p);
     return hipGetLastError();
 }
 

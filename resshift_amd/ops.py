@@ -67,7 +67,8 @@ def conv2d(x0, w_ref, bias=None, x1=None, res=None, stride=1, pad=(1, 1), out_hw
 def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=False):
     """Halo-tile 3x3 conv (igemm4.hip): x [B,H,W,Cin] raw tensor (fp16, or split storage as int32), coef [B,2,Cin] fp32 device
     (GroupNorm affine: scale row, shift row) applied with `act_in` (0 none / 2 SiLU) to x inside the kernel; returns [B,H,W,Cout]
-    in the same storage (with `want_stats` also the [B, max(1, H*W/256), Cout, 2] sums / sums of squares of the stored output)."""
+    in the same storage (with `want_stats` also the [B, slabs, Cout, 2] sums / sums of squares of the stored output; a slab is one
+    pixel tile of the kernel variant or one reduce-kernel slab)."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w_ref.shape[0]
@@ -75,7 +76,12 @@ def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=x.dtype)
     wh, wp = _hostf(w_ref)
     bh, bp = _hostf(bias) if bias is not None else (None, None)
-    st = torch.zeros(B, max(1, H * W // 256), Cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    st = None
+    if want_stats:
+        spx = lib.rs_op_conv3x3_halo_stats_px(B, H, W, Cin, Cout, prec)
+        if spx <= 0:
+            raise RuntimeError("this shape gets no output statistics from the halo kernel")
+        st = torch.zeros(B, (H * W) // spx, Cout, 2, device=x.device, dtype=torch.float32)
     rc = lib.rs_op_conv3x3_halo(x.data_ptr(), coef.data_ptr() if coef is not None else None, act_in, wp, bp,
                                 res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout, prec,
                                 st.data_ptr() if st is not None else None, _lib.current_stream_ptr())
