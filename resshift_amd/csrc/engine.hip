@@ -48,6 +48,9 @@ int rs_clamp_launch(float* x, float lo, float hi, long long cnt, hipStream_t st)
 int rs_win_attn_qkv_supported(int heads, int E);
 int rs_win_attn_qkv_launch(const WinAttnParams* p, hipStream_t st);
 int rs_win_attn_qkv_split_launch(const WinAttnParams* p, hipStream_t st);
+int rs_ae_flash_supported(int C, int T);
+int rs_ae_flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C,
+                       float scale, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                              int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, hipStream_t st);
@@ -164,7 +167,7 @@ struct Exec {
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     // per kernel family of the MFMA path (rs_profile_families): algorithmic FLOPs, launches, and the family of every bracket
-    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_COUNT };
+    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_AEFLASH, F_COUNT };
     double fam_flops[F_COUNT] = {};
     long long fam_launches[F_COUNT] = {};
     std::vector<unsigned char> fam_of;   // family of bracket k (profiling pass only)
@@ -231,6 +234,18 @@ struct Exec {
         }
         if (sp) check(rs_win_attn_qkv_split_launch(&p, st), "win_attn_qkv_split");
         else check(rs_win_attn_qkv_launch(&p, st), "win_attn_qkv");
+        if (e1) (void)hipEventRecord(e1, st);
+    }
+    // streaming AE attention (ae_attn.hip): QK^T and PV of nz images, q / k / v^T read once, o written once
+    void ae_flash(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C, float scale) {
+        const double fl = 4.0 * (double)nz * (double)T * (double)T * (double)C;
+        igemm_flops[0] += fl;
+        fam_note(F_AEFLASH, fl, T, T, C, nz);
+        igemm_bytes += 2.0 * 4.0 * (double)nz * T * C;
+        ++igemm_launches;
+        hipEvent_t e0, e1;
+        bracket(prof, st, e0, e1);
+        check(rs_ae_flash_launch(q, ldq, k, ldk, vt, bv, o, ldo, nz, T, C, scale, st), "ae_flash_attn");
         if (e1) (void)hipEventRecord(e1, st);
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
@@ -901,6 +916,20 @@ struct rs_engine {
         conv1(ex, a.q, n, q);
         conv1(ex, a.k, n, k);
         View o = ex.T(X.B, X.H, X.W, C, dt);
+        // fp16 storage: streaming attention (ae_attn.hip) - S never reaches HBM; RS_AE_FLASH=0 keeps the row-block path below (A/B runs),
+        // which also serves fp32 / split storage and token counts that are not multiples of 128
+        static const bool flash_on = []() { const char* e = getenv("RS_AE_FLASH"); return !(e && e[0] == '0'); }();
+        if (flash_on && dt == RS_F16 && rs_ae_flash_supported(C, T) && a.v.wh) {
+            char* vTa = (char*)ex.raw((size_t)X.B * C * T * 2);
+            if (!ex.dry) {
+                // vT[z][c][t] = sum_k Wv[c][k] n[z][t][k]   (bias added to the attention output: softmax rows sum to 1)
+                gemm_nt(ex, a.v.wh, 0, n.p, (long long)T * C, nullptr, vTa, (long long)C * T, X.B, C, T, C, 1.f, dt, dt);
+                ex.ae_flash(q.p, q.ld, k.p, k.ld, vTa, a.v.bias, o.p, o.ld, X.B, T, C, 1.0f / std::sqrt((float)C));
+            }
+            conv1(ex, a.proj, o, Y, &X);
+            ex.reset(mk);
+            return;
+        }
         // The score matrix is materialised, but never more than `budget` floats of it at a time (4 GiB of fp32 S + the same
         // number of P elements): several images per pass while a whole T x T matrix fits (the 64 x 64 latents of the shipped
         // configs: T = 4096), otherwise one image in blocks of query rows (softmax is row-wise, so row blocks are independent).
@@ -1383,7 +1412,8 @@ int rs_profile_get(rs_engine* e, double* out) {
 }
 
 // per kernel family of the MFMA path, in this order: halo conv fp16 (igemm4), halo conv split, implicit GEMM fp16 (igemm2 / igemm3 /
-// igemm), implicit GEMM split, implicit GEMM fp32, fused qkv + window attention + projection, fused Swin MLP:
+// igemm), implicit GEMM split, implicit GEMM fp32, fused qkv + window attention + projection, fused Swin MLP, their split-storage
+// variants, streaming AE attention:
 // out[3 f + 0] = algorithmic FLOPs, out[3 f + 1] = kernel ms (0 unless profiling was on), out[3 f + 2] = launches.  Returns the family count.
 int rs_profile_families(rs_engine* e, double* out, int cap) {
     if (!e || !out || cap < 3 * Exec::F_COUNT) return -1;
@@ -1807,6 +1837,12 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
     if (rc) fail("fused split qkv + window attention launch rejected the shape (split storage, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
     (void)hipFree(dn);
+    return rc;
+}
+
+int rs_op_ae_flash_attention(const void* q, const void* k, const void* vt, const float* bv_dev, void* o, int nz, int T, int C, void* stream) {
+    const int rc = rs_ae_flash_launch(q, C, k, C, vt, bv_dev, o, C, nz, T, C, 1.0f / std::sqrt((float)C), (hipStream_t)stream);
+    if (rc) fail("streaming AE attention launch rejected the shape (fp16, C in {128, 256, 512}, T a multiple of 128)");
     return rc;
 }
 

@@ -283,12 +283,13 @@ class Engine:
                 "igemm2 / igemm3 / igemm_kernel (implicit GEMM, fp16)", "igemm_split_kernel (implicit GEMM, split storage)",
                 "igemm2 / igemm_kernel<float> (implicit GEMM, exact fp32)", "win_attn_qkv_kernel (fused qkv + window attention + proj)",
                 "swin_mlp_kernel (fused fc1 + GELU + fc2)", "win_attn_qkv_split_kernel (fused qkv + window attention + proj, split storage)",
-                "swin_mlp_split_kernel (fused fc1 + GELU + fc2, split storage)")
+                "swin_mlp_split_kernel (fused fc1 + GELU + fc2, split storage)", "ae_flash_attn_kernel (streaming AE mid-block attention, fp16)")
 
     def profile_families(self):
         """per kernel family of the MFMA path: [(name, algorithmic FLOPs, kernel ms, launches)] of the last native call"""
-        out = (C.c_double * 27)()
-        n = self.lib.rs_profile_families(self._h, out, 27)
+        out = (C.c_double * 3 * len(self.FAMILIES))()
+        out = (C.c_double * (3 * len(self.FAMILIES)))()
+        n = self.lib.rs_profile_families(self._h, out, 3 * len(self.FAMILIES))
         return [(self.FAMILIES[f], out[3 * f], out[3 * f + 1], int(out[3 * f + 2])) for f in range(max(0, n))]
 
     def debug_enable(self, on: bool = True):

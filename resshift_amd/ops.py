@@ -167,6 +167,19 @@ def window_attention_qkv_split(x, wqkv, bqkv, table, heads, shift, wproj=None, b
     return out
 
 
+def ae_flash_attention(q, k, v, bv=None):
+    """q, k, v: [nz, T, C] fp16 device tensors -> softmax(q k^T / sqrt(C)) (v + bv), [nz, T, C] fp16 (streaming kernel, ae_attn.hip)"""
+    lib = _lib.load()
+    nz, T, C = q.shape
+    vt = v.transpose(1, 2).contiguous()
+    bd = bv.to(q.device, torch.float32).contiguous() if bv is not None else None
+    o = torch.empty_like(q)
+    rc = lib.rs_op_ae_flash_attention(q.contiguous().data_ptr(), k.contiguous().data_ptr(), vt.data_ptr(), bd.data_ptr() if bd is not None else None,
+                                      o.data_ptr(), nz, T, C, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_ae_flash_attention")
+    return o
+
+
 def split_pack_rows(w):
     """[rows, K] float weights -> the split-storage operand [rows][K hi | K lo] fp16 (hi = fp16(w), lo = fp16((w - hi) 2^11))"""
     w = w.detach().float()

@@ -571,6 +571,24 @@ def test_window_attention_fused_qkv_split(gpu, hw, shift, fold):
     _close(_unsplit(out2).permute(0, 3, 1, 2), ref2.float(), 5e-6, f"fused split qkv + proj window attention {hw} shift {shift}")
 
 
+@pytest.mark.parametrize("nz,T,C", [(2, 256, 128), (1, 1024, 512), (3, 384, 256), (1, 4096, 512)])
+def test_ae_flash_attention(gpu, nz, T, C):
+    """ae_flash_attn_kernel: softmax(q k^T / sqrt(C)) v + b_v with S kept on chip (online softmax over 64-key blocks, permuted K rows),
+    against torch fp32 on the same fp16 operands; score magnitudes like the AttnBlock's (|s| up to ~10)."""
+    from resshift_amd import ops
+
+    g = torch.Generator().manual_seed(T + C)
+    q = (torch.randn(nz, T, C, generator=g) * 1.5).half()
+    k = (torch.randn(nz, T, C, generator=g) * 1.5).half()
+    v = torch.randn(nz, T, C, generator=g).half()
+    bv = torch.randn(C, generator=g) * 0.3
+    o = ops.ae_flash_attention(q.to(gpu), k.to(gpu), v.to(gpu), bv)
+    torch.cuda.synchronize()
+    w = torch.softmax(torch.bmm(q.float(), k.float().transpose(1, 2)) * C ** -0.5, dim=2)
+    ref = torch.bmm(w, v.float()) + bv
+    _close(o, ref, 3e-3, f"streaming AE attention nz={nz} T={T} C={C}")
+
+
 def test_gemm_nt_batched_and_softmax_split(gpu):
     """AE mid-block attention in split storage: S = q k^T (fp32 out), softmax -> split P, o = P v + b"""
     from resshift_amd import ops
