@@ -783,6 +783,51 @@ def test_ae_attention_at_the_reference_tile_size(gpu, tmp_path):
     assert err < 2e-3
 
 
+def test_streaming_ae_attention_vs_row_block_path(gpu, tmp_path):
+    """ae_flash_attn_kernel (S never in HBM, online softmax) against the row-block path (materialised scores, RS_AE_FLASH=0) on the
+    headline autoencoder at T = 65 536 tokens (a 1024 x 1024 image, the x4 models' 256-pixel tile): two implementations of
+    model.py:179-203 that share nothing but the q / k / v projections."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for name, fl in (("flash", "1"), ("rows", "0")):
+        out = tmp_path / f"{name}.pt"
+        subprocess.run([sys.executable, os.path.join(here, "_ae_once.py"), str(out), "realsr", "1024", "fp16"], check=True,
+                       env=dict(os.environ, RS_AE_FLASH=fl), timeout=600)
+        res[name] = torch.load(out)["z"]
+    err = H.rel_err(res["flash"], res["rows"])
+    print(f"T = 65536 attention, streaming vs row blocks: rel diff {err:.2e}")
+    assert torch.isfinite(res["flash"]).all() and err < 2e-3
+
+
+def test_tiled_path_at_the_reference_default_chop_size_512(gpu):
+    """inference_resshift.py:54-58: the reference's DEFAULT --chop_size 512: one 512 x 512 LR tile = a 512 x 512 latent (64 x the
+    constructed UNet resolution) and a 2048 x 2048 autoencoder image whose mid-block attention runs over T = 262 144 tokens (streaming
+    kernel).  No oracle can hold this size (parity of the same code path: the 128-pixel tile and the off-size tests above): shape,
+    finiteness, range and determinism."""
+    from resshift_amd import ResShiftSampler
+    from resshift_amd.config import ConfigNode
+
+    up, ap, dp = H.realsr_params()
+    usd, asd = H.weights(up, ap)
+    cfg = ConfigNode(model=ConfigNode(target="models.unet.UNetModelSwin", ckpt_path=None, params=up),
+                     diffusion=ConfigNode(target="models.script_util.create_gaussian_diffusion", params=dp),
+                     autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=None, params=ap))
+    s = ResShiftSampler(cfg, sf=4, use_amp=True, chop_size=512, chop_stride=448, chop_bs=1, padding_offset=64, seed=7,
+                        state_dicts={"model": usd, "autoencoder": asd})
+    g = torch.Generator().manual_seed(5)
+    y = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(gpu)
+    out = s.sample_tiled(y, noise_repeat=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1, 3, 2048, 2048) and torch.isfinite(out).all() and out.abs().max().item() <= 1.0
+    again = s.sample_tiled(y, noise_repeat=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, again)
+
+
 def test_tiled_path_at_the_reference_chop_size(gpu):
     """sampler.py:186-208 with the reference's own x4 tile size (inference_resshift.py:149-161, --chop_size 256, stride 224): a
     300 x 280 LR input -> four 256 x 256 LR tiles, each a 256 x 256 latent (UNet at 4x the constructed resolution: per-size
