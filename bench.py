@@ -230,6 +230,30 @@ def main():
     value = world * B * args.steps / elapsed
     log(f"timed region done: {ms_per_step:.1f} ms/step, {value:.2f} img/s")
 
+    # ---- N > 1: the parity-qualified policy timed across all ranks exactly like the headline (barriers, max over ranks), so that the
+    # scaling curve exists for the credited policy too.  Its parity against the CPU oracle is established by the N = 1 line
+    # (`value_at_parity`) and the GPU tests; this leg only times it.
+    value_parity_policy = None
+    if world > 1 and args.precision != PARITY_POLICY:
+        polp = policy_args(PARITY_POLICY, steps)
+        for _ in range(max(1, args.warmup)):
+            run(polp)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run(polp)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        el_p = sharding.allreduce_max(time.perf_counter() - t0, dev)
+        value_parity_policy = {"value": round(world * B * args.steps / el_p, 3), "unit": "images/sec", "ms_per_step": round(el_p / args.steps * 1e3, 3),
+                               "policy": PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", "n_gpus": world, "steps": args.steps,
+                               "note": "timed like `value` (barrier-bracketed, max over ranks); the policy's parity against the CPU oracle is "
+                                       "checked in the N = 1 line (`value_at_parity`) and in tests/test_engine_gpu.py"}
+        log(f"parity policy across {world} ranks: {value_parity_policy['value']} img/s")
+
     # ---- roofline of the dominant kernel family (MFMA implicit GEMM) and of the GroupNorm family, measured in a dedicated
     # pass with hipEvents on the launch stream
     roofline = None
@@ -263,7 +287,7 @@ def main():
             else:
                 traffic_note = "profiles/ PMC file was collected on different kernel sources: not reported"
         roofline = {
-            "bound": "mfma", "kernel": "igemm4_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / win_attn_qkv_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels)",
+            "bound": "mfma", "kernel": "igemm4_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / win_attn_qkv*_kernel / ae_flash_attn_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
             "achieved": round(achieved, 2), "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
             "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_note": traffic_note,
             "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),
@@ -431,7 +455,7 @@ def main():
                       "per_rank": [{"rank": r, "device": int(v[1]), "images_per_sec": round(B * args.steps / v[0], 3)} for r, v in enumerate(per_rank)],
                       "weight_broadcast_bytes": int(getattr(eng, "broadcast_bytes", 0)),
                       "weight_broadcast_ms": round(1e3 * float(getattr(eng, "broadcast_s", 0.0)), 3)},
-            "value_at_parity": value_at_parity,
+            "value_at_parity": value_at_parity, "value_parity_policy": value_parity_policy,
             "value_at_parity_mixed": next(({"value": p["images_per_sec"], "unit": "images/sec", "policy": p["policy"], "image_psnr_db": p["image_psnr_db"],
                                             "vq_code_agreement": p["vq_code_agreement"], "images": p["images"],
                                             "meets_criterion": bool(p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999)}
