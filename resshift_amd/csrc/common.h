@@ -235,11 +235,11 @@ struct WinAttnParams {
     float scale;
     // fused qkv projection (win_attn_qkv_kernel): normalised tokens instead of a qkv tensor
     const void* x;        // [B,H,W,ldx] fp16, features 0..E-1
-    const void* wqkv;     // [3E][E] fp16 row-major (swin_transformer.py:85 qkv Linear)
+    const void* wqkv;     // [3E][E] weight of the qkv Linear (swin_transformer.py:85) in FRAGMENT-MAJOR order (engine.hip ConvW::wh_frag / ws_frag)
     const float* bqkv;    // [3E]
     int ldx;
     // optional fused output projection + residual (swin_transformer.py:141-143,277): out = res + proj(attention)
-    const void* wproj;    // [E][E] fp16 row-major, null -> `out` receives the attention result itself
+    const void* wproj;    // [E][E] in fragment-major order, null -> `out` receives the attention result itself
     const float* bproj;   // [E]
     const void* res;      // [B,H,W,ldres] fp16 shortcut, read at the same (un-shifted) pixels the result is written to
     int ldres;

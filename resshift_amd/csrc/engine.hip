@@ -70,6 +70,41 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
+// Fragment-major order of a [N][K] weight (ConvW::wh_frag / ws_frag): element e of lane (lr = lane & 15, lg = lane >> 4) of (16-row block
+// nb, k step ks) is W[16 nb + lr][32 ks + 8 lg + e].  `hi(n, k)` / `lo(n, k)` fetch the fp16 planes; with a lo plane every (nb, ks) holds
+// 1 KB of hi followed by 1 KB of lo.
+template <class FH, class FL>
+static void frag_major_fill(int N, int K, f16* dst, bool with_lo, FH hi, FL lo) {
+    const int KS = K / 32, parts = with_lo ? 2 : 1;
+    for (int nb = 0; nb < N / 16; ++nb)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * nb + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+                    const size_t o = (((size_t)(nb * KS + ks) * parts) * 64 + lane) * 8 + e;
+                    dst[o] = hi(n, k);
+                    if (with_lo) dst[o + 512] = lo(n, k);
+                }
+}
+// from the reference fp32 weight: fp16 copy (out16) or split (hi, lo) copy (outsplit), rounded exactly like add_conv's packers
+static void rs_pack_frag_major(const float* w, int N, int K, f16* out16, f16* outsplit) {
+    if (out16) frag_major_fill(N, K, out16, false, [&](int n, int k) { return (f16)w[(size_t)n * K + k]; }, [&](int, int) { return (f16)0.f; });
+    if (outsplit)
+        frag_major_fill(N, K, outsplit, true, [&](int n, int k) { f16 h, l; rs_split(w[(size_t)n * K + k], h, l); return h; },
+                        [&](int n, int k) { f16 h, l; rs_split(w[(size_t)n * K + k], h, l); return l; });
+}
+// from a row-major DEVICE operand (op-level test entries): rows of `ld` halfs, lo plane at +lo_off halfs (< 0: fp16 only) -> device copy
+static void* frag_major_from_device_rows(const void* wdev, int N, int K, int ld, int lo_off) {
+    std::vector<f16> rows((size_t)N * ld), out((size_t)N * K * (lo_off >= 0 ? 2 : 1));
+    if (hipMemcpy(rows.data(), wdev, rows.size() * sizeof(f16), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    frag_major_fill(N, K, out.data(), lo_off >= 0, [&](int n, int k) { return rows[(size_t)n * ld + k]; },
+                    [&](int n, int k) { return rows[(size_t)n * ld + (lo_off >= 0 ? lo_off : 0) + k]; });
+    void* d = nullptr;
+    if (hipMalloc(&d, out.size() * sizeof(f16)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, out.data(), out.size() * sizeof(f16), hipMemcpyHostToDevice);
+    return d;
+}
+
 struct View {
     void* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0, dt = RS_F16;
     // optional per-channel partial statistics of this tensor, [B][stS][stld][2] floats (IGemmParams::ystats): set by whoever
@@ -100,8 +135,12 @@ struct Blob {
 struct ConvW {
     int Cin = 0, CinP = 0, Cout = 0, KH = 1, KW = 1;
     void* wh = nullptr; void* wf = nullptr; void* ws = nullptr; float* wd = nullptr; float* bias = nullptr;
+    // fragment-major copies for the fused window-attention kernels (add_frag_copies): [16-row block][32-wide k step][lane] x 16 B (fp16;
+    // split: 1 KB of hi then 1 KB of lo per block and k step), so that a wave's A-operand fragment is ONE contiguous 1 KB read
+    void* wh_frag = nullptr; void* ws_frag = nullptr;
     bool direct = false;
     const void* w_for(int dt) const { return dt == RS_F16 ? wh : (dt == RS_F16S ? ws : wf); }
+    const void* w_frag_for(int dt) const { return dt == RS_F16 ? wh_frag : (dt == RS_F16S ? ws_frag : nullptr); }
 };
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResBlockW { GNW n1, n2; ConvW c1, c2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int film_off = -1; ConvW emb; };
@@ -395,6 +434,29 @@ struct rs_engine {
         if (has_bias) c.bias = add_f32(prefix + ".bias", Cout);
         return c;
     }
+    // Fragment-major copies of a 1x1 weight [N][K] (N % 16 == 0, K % 32 == 0) for win_attn_qkv_kernel / win_attn_qkv_split_kernel: lane
+    // (lr, lg) of the wave that multiplies rows 16 nb .. 16 nb + 15 with k step ks reads W[16 nb + lr][32 ks + 8 lg .. + 7] - from the
+    // row-major weight that is 16 different cache lines per wave instruction, from this copy 8 full ones.
+    void add_frag_copies(ConvW& c, const std::string& prefix) {
+        const int N = c.Cout, K = c.Cin;
+        if (c.KH != 1 || c.KW != 1 || (N % 16) || (K % 32)) return;
+        const std::string wkey = prefix + ".weight";
+        const size_t n = (size_t)N * K;
+        auto get = [this, wkey, n]() -> const float* {
+            const HostTensor* t = find(wkey);
+            return (t && t->data.size() == n) ? t->data.data() : nullptr;
+        };
+        if (cfg.enable_f16)
+            c.wh_frag = blob.add(n * 2, [=](char* dst) {
+                const float* w = get(); if (!w) return;
+                rs_pack_frag_major(w, N, K, (f16*)dst, nullptr);
+            });
+        if (cfg.enable_split)
+            c.ws_frag = blob.add(n * 4, [=](char* dst) {
+                const float* w = get(); if (!w) return;
+                rs_pack_frag_major(w, N, K, nullptr, (f16*)dst);
+            });
+    }
     // plain fp32 linear kept in the reference [N][K] layout (time embedding MLP, emb_layers)
     ConvW add_linear_f32(const std::string& prefix, int K, int N) {
         ConvW c; c.Cin = K; c.Cout = N;
@@ -429,6 +491,7 @@ struct rs_engine {
             s.shift = (d % 2 == 1 && ds > u.window_size) ? u.window_size / 2 : 0;
             s.n1 = add_gn(q + ".norm1", E);
             s.qkv = add_conv(q + ".attn.qkv", E, 3 * E, 1, 1);
+            add_frag_copies(s.qkv, q + ".attn.qkv");
             const std::string tkey = q + ".attn.relative_position_bias_table";
             s.bias_t = (float*)blob.add((size_t)heads * 64 * 64 * 4, [&, tkey, heads](char* dst) {
                 const HostTensor* t = find(tkey);
@@ -454,6 +517,7 @@ struct rs_engine {
                         }
             });
             s.proj = add_conv(q + ".attn.proj", E, E, 1, 1);
+            add_frag_copies(s.proj, q + ".attn.proj");
             s.n2 = add_gn(q + ".norm2", E);
             s.fc1 = add_conv(q + ".mlp.fc1", E, hidden, 1, 1);
             s.fc2 = add_conv(q + ".mlp.fc2", hidden, E, 1, 1);
@@ -819,7 +883,7 @@ struct rs_engine {
             // split storage: the same fusion in win_attn_split.hip (RS_ATTN_FUSED_SPLIT=0: separate qkv GEMM, attention, projection GEMM)
             static const int attn_fused_split = []() { const char* v = getenv("RS_ATTN_FUSED_SPLIT"); return v ? atoi(v) : 1; }();
             const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.trace &&
-                                  ((attn_fused && X.dt == RS_F16 && s.qkv.wh) || (attn_fused_split && X.dt == RS_F16S && s.qkv.ws && s.proj.ws));
+                                  ((attn_fused && X.dt == RS_F16 && s.qkv.wh_frag) || (attn_fused_split && X.dt == RS_F16S && s.qkv.ws_frag && s.proj.ws_frag));
             const bool fold1 = fuse_qkv && gn_fold;
             View n;
             float* coef1 = nullptr;
@@ -831,7 +895,7 @@ struct rs_engine {
                 conv1(ex, s.qkv, n, qkv);
                 ex.tr(bp + "qkv", qkv);
             }
-            const bool fuse_proj = fuse_qkv && (X.dt == RS_F16S || (attn_fused >= 2 && s.proj.wh));   // ... and the output projection + shortcut as well
+            const bool fuse_proj = fuse_qkv && (X.dt == RS_F16S || (attn_fused >= 2 && s.proj.wh_frag));   // ... and the output projection + shortcut as well
             View a, e2;
             if (fuse_proj) e2 = ex.T(X.B, X.H, X.W, E, X.dt); else a = ex.T(X.B, X.H, X.W, E, X.dt);
             // RS_GN_SWIN_STATS=1: the fused kernels' epilogues leave the statistics of their outputs for the GroupNorm that
@@ -851,8 +915,8 @@ struct rs_engine {
                     p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
                     p.scale = 1.0f / std::sqrt((float)(E / heads));
                     if (fold1) { p.x = e.p; p.ldx = e.ld; p.xcoef = coef1; } else { p.x = n.p; p.ldx = n.ld; }
-                    p.wqkv = s.qkv.w_for(X.dt); p.bqkv = s.qkv.bias;
-                    if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.w_for(X.dt); p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld;
+                    p.wqkv = s.qkv.w_frag_for(X.dt); p.bqkv = s.qkv.bias;
+                    if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.w_frag_for(X.dt); p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld;
                                      p.ystats = e2.st; p.ystats_ld = e2.stld; }
                     else { p.out = a.p; p.ldo = a.ld; }
                     ex.win_attn_qkv(p, E, X.dt);
@@ -1808,12 +1872,16 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
     float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
     WinAttnParams p{};
     p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
-    p.x = x; p.wqkv = wqkv_dev; p.bqkv = bqkv_dev; p.ldx = heads * 32;
-    p.wproj = wproj_dev; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
-    const int rc = rs_win_attn_qkv_launch(&p, st);
+    // the kernel reads its weights in fragment-major order (ConvW::wh_frag): repack the caller's row-major operands
+    const int E = heads * 32;
+    void* wq_f = frag_major_from_device_rows(wqkv_dev, 3 * E, E, E, -1);
+    void* wp_f = wproj_dev ? frag_major_from_device_rows(wproj_dev, E, E, E, -1) : nullptr;
+    p.x = x; p.wqkv = wq_f; p.bqkv = bqkv_dev; p.ldx = heads * 32;
+    p.wproj = wp_f; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
+    const int rc = (wq_f && (wp_f || !wproj_dev)) ? rs_win_attn_qkv_launch(&p, st) : -1;
     if (rc) fail("fused qkv + window attention launch rejected the shape (fp16, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
-    (void)hipFree(dn);
+    (void)hipFree(dn); (void)hipFree(wq_f); (void)hipFree(wp_f);
     return rc;
 }
 
@@ -1831,12 +1899,16 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
     float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
     WinAttnParams p{};
     p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
-    p.x = x; p.wqkv = wqkv_dev; p.bqkv = bqkv_dev; p.ldx = heads * 32; p.xcoef = xcoef_dev;
-    p.wproj = wproj_dev; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
-    const int rc = rs_win_attn_qkv_split_launch(&p, st);
+    // fragment-major (hi, lo) weights (ConvW::ws_frag) from the caller's rows [K hi | K lo]
+    const int E = heads * 32;
+    void* wq_f = frag_major_from_device_rows(wqkv_dev, 3 * E, E, 2 * E, E);
+    void* wp_f = wproj_dev ? frag_major_from_device_rows(wproj_dev, E, E, 2 * E, E) : nullptr;
+    p.x = x; p.wqkv = wq_f; p.bqkv = bqkv_dev; p.ldx = heads * 32; p.xcoef = xcoef_dev;
+    p.wproj = wp_f; p.bproj = bproj_dev; p.res = res; p.ldres = heads * 32;
+    const int rc = (wq_f && (wp_f || !wproj_dev)) ? rs_win_attn_qkv_split_launch(&p, st) : -1;
     if (rc) fail("fused split qkv + window attention launch rejected the shape (split storage, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
-    (void)hipFree(dn);
+    (void)hipFree(dn); (void)hipFree(wq_f); (void)hipFree(wp_f);
     return rc;
 }
 

@@ -755,13 +755,17 @@ __device__ __forceinline__ void lds_dma16_na(__amdgpu_buffer_rsrc_t r, char* lds
 // on the 64x64 level) never exists.
 #ifdef RS_SPLIT_ABLATE
 __device__ int g_attn_abl = 0;   // timing ablation (RS_ATTN_ABL=1, ablate builds): every weight fragment comes from one cached line
+__device__ long long g_attn_clk[16 * 4096];   // phase stamps of wave 0 of the first 4096 workgroups
+#define RS_ATTN_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) { const int wg_ = blockIdx.y * gridDim.x + blockIdx.x; if (wg_ < 4096) g_attn_clk[16 * wg_ + (k)] = clock64(); } } while (0)
+#else
+#define RS_ATTN_STAMP(k)
 #endif
 // NW windows per workgroup (1 or 2): a wave's q / k / v / proj weight fragments are fetched from L2 once and applied to the tokens
 // of NW windows.  The kernel is bound by that weight stream (295 KB per window, 2.4 GB per launch on the 64 x 64 level at batch
 // 32 - with every fragment read from one cached line instead it is 29 % faster, profiles/r2_swin_mlp_split_ablation.txt), so two
 // windows per workgroup halve its dominant traffic; the attention itself runs window after window on the same registers.
 template <int NW>
-__global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsigned x_bytes) {
+__global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsigned x_bytes, unsigned res_bytes) {
     constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
     constexpr int XS_STAGE = NT * 128;                       // 64 token rows x 128 B per 64-wide K stage
     constexpr int XS_WIN = 3 * XS_STAGE;                     // token tile of one window
@@ -772,7 +776,21 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     const int lr = lane & 15, lg = lane >> 4;
     const int nwx = p.W / WS;
     const int b = blockIdx.y;
+    RS_ATTN_STAMP(0);
     auto vt_of = [&](int w) { return (f16*)(smem + NW * XS_WIN) + (size_t)(w * 6 + h) * HD * VP; };   // [HD][VP] of (window, head)
+    // The relative position bias of (query i, key j) depends on (y_i - y_j, x_i - x_j) only: 225 values per head
+    // (swin_transformer.py:93-102).  They are copied once per workgroup from the dense [h][i][j] table into LDS (5.4 KB) and the softmax
+    // reads them from there with constant offsets - instead of 16 KB per head and window through L2 (a third of this kernel's traffic).
+    constexpr int BT_BYTES = 5632;                           // 6 x 225 floats, padded to a multiple of 256 B
+    float* const btab = (float*)(smem + NW * (XS_WIN + 6 * HD * VP * 2));
+    // residual / output tile of window w (fused projection only): the shortcut rows arrive here by LDS-DMA (token tile format), the
+    // projection adds its result in place and the finished tile leaves as whole 128-byte lines
+    auto rt_of = [&](int w) { return smem + NW * (XS_WIN + 6 * HD * VP * 2) + BT_BYTES + w * XS_WIN; };
+    for (int e = tid; e < 6 * 225; e += 384) {
+        const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
+        const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
+        btab[e] = p.bias_n[(hh * NT + i) * NT + j];
+    }
     auto win_y = [&](int w) { return (int)(blockIdx.x * NW + w) / nwx; };
     auto pixel = [&](int w, int t) -> long long {
         const int wi = blockIdx.x * NW + w;
@@ -793,10 +811,23 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                 const unsigned off = (unsigned)(pixel(w, grp * 8 + rsub) * p.ldx + st * 64 + kcp * 8) * 2u;
                 lds_dma16_na(rx, smem + w * XS_WIN + st * XS_STAGE + (grp * 8) * 128, off);
             }
+        if (p.wproj && p.res) {   // the shortcut's rows: in flight until the projection epilogue
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int it = h * 4 + q, st = it >> 3, grp = it & 7;
+                    const unsigned off = (unsigned)(pixel(w, grp * 8 + rsub) * p.ldres + st * 64 + kcp * 8) * 2u;
+                    lds_dma16_na(rr, rt_of(w) + st * XS_STAGE + (grp * 8) * 128, off);
+                }
+        }
     }
     const f16* wq = (const f16*)p.wqkv;
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
-    // this head's 32 output features starting at weight row n0: fragments straight from L2 in MFMA A-operand layout
+    // this head's 32 output features starting at weight row n0: fragments straight from L2 in MFMA A-operand layout.  The weights come
+    // in FRAGMENT-MAJOR order (engine.hip ConvW::wh_frag: [16-row block][k step][lane] x 16 B): one contiguous 1 KB per wave instruction
+    // (8 cache lines) where the row-major weight costs 16 lines of which half the bytes are used
     auto load_w = [&](const f16* wsrc, int n0, f16x8 (&wf)[2][KS]) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -805,7 +836,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
 #ifdef RS_SPLIT_ABLATE
                 if (g_attn_abl) { wf[f][ks] = *(const f16x8*)(wsrc + lg * 8); continue; }
 #endif
-                wf[f][ks] = *(const f16x8*)(wsrc + (long long)(n0 + 16 * f + lr) * E + ks * 32 + lg * 8);
+                wf[f][ks] = *(const f16x8*)(wsrc + ((long long)((n0 >> 4) + f) * KS + ks) * 512 + lane * 8);   // fragment-major: 1 KB per wave
             }
     };
     // one projection pass over the token tile of window w -> acc[2 feature frags][4 token frags] (bias in the accumulator)
@@ -836,6 +867,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the windows' tokens are in LDS
+    RS_ATTN_STAMP(1);
     if (p.xcoef) {
         // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c], rounded to fp16 exactly where the separate apply kernel
         // rounds.  Per window 64 rows x 24 chunks of 8 channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
@@ -857,6 +889,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
             }
         __syncthreads();
     }
+    RS_ATTN_STAMP(2);
     f16x8 kf[NW][4], qf[NW][4];
     {
         f16x8 wf[2][KS];
@@ -865,9 +898,11 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         load_w(wq, h * HD, wf);            // q_h: lane (lr,lg) holds d = {4lg+r, 16+4lg+r} of token 16fi+lr
 #pragma unroll
         for (int w = 0; w < NW; ++w) { project(w, wf, p.bqkv, h * HD, acc); pack(acc, qf[w]); __builtin_amdgcn_sched_barrier(0); }
+        RS_ATTN_STAMP(3);
         load_w(wq, E + h * HD, wf);        // k_h: the same d set per lane -> a consistent contraction order for S^T
 #pragma unroll
         for (int w = 0; w < NW; ++w) { project(w, wf, p.bqkv, E + h * HD, acc); pack(acc, kf[w]); __builtin_amdgcn_sched_barrier(0); }
+        RS_ATTN_STAMP(4);
         load_w(wq, 2 * E + h * HD, wf);    // v_h -> V^T[d][token] in LDS
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -882,8 +917,11 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                     for (int r = 0; r < 4; ++r) vt[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = (f16)acc[f][ft][r];
         }
     }
+    RS_ATTN_STAMP(5);
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tiles (they are overwritten below)
-    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+    RS_ATTN_STAMP(6);
+    // bias of (i = 16 fi + lr, j = 16 fj + 4 lg + r) = tb[30 (fi - fj) - r]
+    const float* tb = btab + h * 225 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
     f16* out = (f16*)p.out;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -905,14 +943,12 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         float inv[4];
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
-            const int i = 16 * fi + lr;
             float m = -3.0e38f;
 #pragma unroll
             for (int fj = 0; fj < 4; ++fj) {
-                const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                    float v = fmaf(s[fj][fi][r], p.scale, tb[30 * (fi - fj) - r]);
                     if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
                     s[fj][fi][r] = v;
                     m = fmaxf(m, v);
@@ -970,27 +1006,19 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                 // fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format)
                 else *(f16x4*)(smem + w * XS_WIN + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2) = hv;
             }
+        RS_ATTN_STAMP(7 + w);
     }
     if (!p.wproj) return;
     // ---- fused output projection: wave h produces output features 32h .. 32h+31 for all tokens: 48 MFMAs per window, weights
     // straight from L2 like the qkv passes
     f16x8 wf2[2][KS];
     load_w((const f16*)p.wproj, h * HD, wf2);
-    const f16* res = (const f16*)p.res;
+    const bool has_res = p.res != nullptr;
     __syncthreads();   // all heads' attention results are in LDS
+    RS_ATTN_STAMP(9);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         __builtin_amdgcn_sched_barrier(0);
-        long long pix[4];
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) pix[fi] = pixel(w, 16 * fi + lr);
-        f16x4 rv[2][4];
-        if (res) {
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) rv[f][fi] = *(const f16x4*)(res + pix[fi] * p.ldres + h * HD + 16 * f + 4 * lg);
-        }
         f32x4 acc2[2][4];
         project(w, wf2, p.bproj, h * HD, acc2);
         float s1[2][4], s2[2][4];   // per-channel sums of the STORED values over this lane's four tokens
@@ -998,18 +1026,22 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
+        char* const rt = rt_of(w);
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                f16x4 hv;
+                // cell of (token t, features c .. c + 3) in the residual / output tile: read and rewritten by this lane only
+                const int t = 16 * fi + lr, c = h * HD + 16 * f + 4 * lg;
+                f16x4* cell = (f16x4*)(rt + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2);
+                f16x4 hv, rv = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                if (has_res) rv = *cell;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hv[r] = (f16)(acc2[f][fi][r] + (res ? (float)rv[f][fi][r] : 0.f));
-                    const float sv = (float)hv[r];
-                    s1[f][r] += sv; s2[f][r] = fmaf(sv, sv, s2[f][r]);
+                    hv[r] = (f16)(acc2[f][fi][r] + (float)rv[r]);
+                    if (p.ystats) { const float sv = (float)hv[r]; s1[f][r] += sv; s2[f][r] = fmaf(sv, sv, s2[f][r]); }
                 }
-                *(f16x4*)(out + pix[fi] * p.ldo + h * HD + 16 * f + 4 * lg) = hv;
+                *cell = hv;
             }
         if (p.ystats) {   // statistics for norm2: the wave holds its 32 features of all 64 tokens of the window
             const int wi = blockIdx.x * NW + w;
@@ -1025,9 +1057,42 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                 }
         }
     }
+    __syncthreads();   // the output tiles are complete
+    // whole rows out: per window 24 pieces of 8 token rows x 128 B (8 full cache lines per wave instruction), 4 per wave
+    {
+        const int rsub = lane >> 3, ps = lane & 7, chunk = ps ^ (rsub & 7);
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int it = h * 4 + q, st = it >> 3, grp = it & 7;
+                const f16x8 v = *(const f16x8*)(rt_of(w) + st * XS_STAGE + (grp * 8 + rsub) * 128 + ps * 16);
+                *(f16x8*)(out + pixel(w, grp * 8 + rsub) * p.ldo + st * 64 + chunk * 8) = v;
+            }
+    }
+    RS_ATTN_STAMP(10);
 }
 
+
 }  // namespace
+
+#ifdef RS_SPLIT_ABLATE
+// ablate builds: mean cycles between consecutive stamps (0 .. nst-1) of wave 0 over the first `nwg` workgroups of the last launch
+extern "C" int rs_attn_phase_cycles(int nwg, int nst, double* out) {
+    static long long h[16 * 4096];
+    if (nwg < 1 || nwg > 4096 || nst < 2 || nst > 16) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_clk), sizeof(long long) * 16 * nwg) != hipSuccess) return -1;
+    for (int k = 0; k + 1 < nst; ++k) {
+        out[k] = 0.0;
+        for (int i = 0; i < nwg; ++i) out[k] += (double)(h[16 * i + k + 1] - h[16 * i + k]) / nwg;
+    }
+    long long lo = h[0], hi = h[nst - 1];   // span of the launch: first start .. last end over the stamped workgroups
+    for (int i = 0; i < nwg; ++i) { lo = h[16 * i] < lo ? h[16 * i] : lo; hi = h[16 * i + nst - 1] > hi ? h[16 * i + nst - 1] : hi; }
+    out[nst - 1] = (double)(hi - lo);
+    return 0;
+}
+#endif
 
 // fused qkv projection + window attention (fp16, 6 heads of 32): x, wqkv, bqkv, ldx of the parameter block are used, qkv is not
 extern "C" int rs_win_attn_qkv_supported(int heads, int E) { return heads == 6 && E == 192; }
@@ -1042,21 +1107,28 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     static const int nw_max = []() { const char* v = getenv("RS_ATTN_NW"); return v ? atoi(v) : 2; }();
     const int nwin = (p.H / 8) * (p.W / 8);
     const int NW = (nw_max >= 2 && nwin % 2 == 0) ? 2 : 1;
-    const size_t lds = (size_t)NW * (3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16));
+    const size_t rb = p.res ? (size_t)p.B * p.H * p.W * p.ldres * 2 : 0;
+    if (rb >= 0xF0000000ull || (p.wproj && p.res && (p.ldres % 8))) return -2;
+    // token tiles + V^T + the bias table (+ with the fused projection one residual / output tile per window)
+    const size_t lds = (size_t)NW * (3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16)) + 5632 + (p.wproj ? (size_t)NW * 3 * 64 * 128 : 0);
 #ifdef RS_SPLIT_ABLATE
     {
         static const int abl = []() { const char* v = getenv("RS_ATTN_ABL"); const int a = v ? atoi(v) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &a, sizeof(int)); return a; }();
         (void)abl;
     }
 #endif
-    if (NW == 2) {
+    {   // dynamic LDS above 64 KB needs the attribute: set once per device to the largest layout (fused projection)
         static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
-    } else {
-        hipLaunchKernelGGL(win_attn_qkv_kernel<1>, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+        bool& attr_set = attr_done[rs_device_slot()];
+        if (!attr_set) {
+            const int per_win = 3 * 64 * 128 + 6 * 32 * (64 + 8) * 2 + 3 * 64 * 128;
+            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * per_win + 5632);
+            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, per_win + 5632);
+            attr_set = true;
+        }
     }
+    if (NW == 2) hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
+    else hipLaunchKernelGGL(win_attn_qkv_kernel<1>, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -24,7 +24,14 @@ __device__ __forceinline__ void lds_dma16_ws(__amdgpu_buffer_rsrc_t r, char* lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr3_t)lds, 16, voff, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p, unsigned x_bytes) {
+#ifdef RS_SPLIT_ABLATE
+__device__ long long g_attns_clk[16 * 4096];   // phase stamps of wave 0 of the first 4096 workgroups
+#define RS_ATTN_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) { const int wg_ = blockIdx.y * gridDim.x + blockIdx.x; if (wg_ < 4096) g_attns_clk[16 * wg_ + (k)] = clock64(); } } while (0)
+#else
+#define RS_ATTN_STAMP(k)
+#endif
+
+__global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p, unsigned x_bytes, unsigned res_bytes) {
     constexpr int HD = 32, WS = 8, NT = 64, VP = NT + 8, E = 192, KS = E / 32;
     constexpr int XS_STAGE = NT * 128;          // 64 token rows x 128 B per 64-wide K stage
     constexpr int XS_PLANE = 3 * XS_STAGE;      // hi (or lo) plane of the token tile
@@ -37,8 +44,20 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     const int nwx = p.W / WS;
     const int b = blockIdx.y;
     const int wy = blockIdx.x / nwx, wx = blockIdx.x - wy * nwx;
+    RS_ATTN_STAMP(0);
     f16* vth = (f16*)(smem + 2 * XS_PLANE) + (size_t)h * VT_HEAD;
     f16* vtl = vth + HD * VP;
+    // relative position bias: the 225 distinct values per head (swin_transformer.py:93-102) copied once from the dense [h][i][j] table
+    // into LDS; the softmax reads them with constant offsets instead of 96 KB per window through L2 (as win_attn_qkv_kernel)
+    float* const btab = (float*)(smem + 2 * XS_PLANE + 6 * VT_HEAD * 2);
+    // residual / output tile (fused projection only; hi plane, lo plane in the token tile format): the shortcut's rows arrive by LDS-DMA,
+    // the projection adds its result in place and the finished tile leaves as whole 128-byte lines
+    char* const rt = smem + 2 * XS_PLANE + 6 * VT_HEAD * 2 + 5632;
+    for (int e = tid; e < 6 * 225; e += 384) {
+        const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
+        const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
+        btab[e] = p.bias_n[(hh * NT + i) * NT + j];
+    }
     const int shift = p.shift, H = p.H, W = p.W;
     auto pixel = [&](int t) -> long long {
         int sy = wy * WS + (t >> 3) + shift; if (sy >= H) sy -= H;
@@ -56,6 +75,15 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldx * 2 + plane * p.ldx + st * 64 + kcp * 8) * 2u;
             lds_dma16_ws(rx, smem + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
         }
+        if (p.wproj && p.res) {   // the shortcut's rows: in flight until the projection epilogue
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int it = h * 8 + q, plane = it / 24, r24 = it - plane * 24, st = r24 >> 3, grp = r24 & 7;
+                const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldres * 2 + plane * p.ldres + st * 64 + kcp * 8) * 2u;
+                lds_dma16_ws(rr, rt + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
+            }
+        }
     }
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
     // one projection pass over the token tile: 32 output features starting at weight row n0 (rows [K hi | K lo], K = E) ->
@@ -66,11 +94,12 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     auto load_w = [&](const f16* wsrc, int n0, f16x8 (&wh)[2][KS], f16x8 (&wl)[2][KS]) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const f16* wr = wsrc + (long long)(n0 + 16 * f + lr) * (2 * E) + lg * 8;
+            // fragment-major weights (engine.hip ConvW::ws_frag): per (16-row block, k step) 1 KB of hi then 1 KB of lo, lane-contiguous
+            const f16* wr = wsrc + (long long)((n0 >> 4) + f) * KS * 1024 + lane * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                wh[f][ks] = *(const f16x8*)(wr + ks * 32);
-                wl[f][ks] = *(const f16x8*)(wr + E + ks * 32);
+                wh[f][ks] = *(const f16x8*)(wr + ks * 1024);
+                wl[f][ks] = *(const f16x8*)(wr + ks * 1024 + 512);
             }
         }
     };
@@ -122,6 +151,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     load_w(wq, h * HD, wfh, wfl);     // q_h weights: requested together with the token tile, one L2 round trip for both
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the window's tokens are in LDS
+    RS_ATTN_STAMP(1);
     if (p.xcoef) {
         // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c] on the joined value, re-split.  64 rows x 24 chunks of 8
         // channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
@@ -146,6 +176,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         }
         __syncthreads();
     }
+    RS_ATTN_STAMP(2);
     f16x8 kh[4], kl[4], qh[4], ql[4];
     {
         f32x4 acc[2][4];
@@ -153,12 +184,16 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         load_w(wq, E + h * HD, wfh, wfl);
         pack(acc, qh, ql);
         __builtin_amdgcn_sched_barrier(0);
+        RS_ATTN_STAMP(3);
         project(wfh, wfl, p.bqkv, E + h * HD, acc);        // k_h: the same d set per lane -> a consistent contraction order for S^T
         load_w(wq, 2 * E + h * HD, wfh, wfl);
         pack(acc, kh, kl);
         __builtin_amdgcn_sched_barrier(0);
+        RS_ATTN_STAMP(4);
         project(wfh, wfl, p.bqkv, 2 * E + h * HD, acc);    // v_h -> V^T[d][token] (hi, lo) in LDS
-        if (p.wproj) load_w((const f16*)p.wproj, h * HD, wfh, wfl);   // projection weights: in flight during the whole attention
+#ifdef RS_ATTN_SPLIT_EARLYW   // (projection weights in flight during the whole attention: 96 registers the softmax then spills; measured equal)
+        if (p.wproj) load_w((const f16*)p.wproj, h * HD, wfh, wfl);
+#endif
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -171,7 +206,9 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
                     vtl[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = c;
                 }
     }
+    RS_ATTN_STAMP(5);
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tile (it is overwritten below)
+    RS_ATTN_STAMP(6);
     f32x4 s[4][4];  // [fj][fi]
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj)
@@ -191,17 +228,17 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
     }
     float inv[4];
-    const float* bn = p.bias_n + (long long)h * NT * NT;  // [i][j]
+    // bias of (i = 16 fi + lr, j = 16 fj + 4 lg + r) = tb[30 (fi - fj) - r]
+    const float* tb = btab + h * 225 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi) {
-        const int i = 16 * fi + lr;
+        __builtin_amdgcn_sched_barrier(0);   // one query fragment's 16 table reads at a time (all 64 up front do not fit 256 registers)
         float m = -3.0e38f;
 #pragma unroll
         for (int fj = 0; fj < 4; ++fj) {
-            const f32x4 bv = *(const f32x4*)(bn + i * NT + 16 * fj + 4 * lg);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = fmaf(s[fj][fi][r], p.scale, bv[r]);
+                float v = fmaf(s[fj][fi][r], p.scale, tb[30 * (fi - fj) - r]);
                 if (shift > 0 && rid_j[r] != rid_i) v += -100.0f;
                 s[fj][fi][r] = v;
                 m = fmaxf(m, v);
@@ -222,6 +259,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         l += __shfl_xor(l, 32);
         inv[fi] = 1.0f / l;
     }
+    RS_ATTN_STAMP(7);   // scores + softmax done
     f32x4 om[2][4], oc[2][4];    // [fd][fi] main / cross
 #pragma unroll
     for (int fd = 0; fd < 2; ++fd)
@@ -281,24 +319,14 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             }
         }
     if (!p.wproj) return;
+    RS_ATTN_STAMP(8);   // P V done, results in LDS
     // ---- fused output projection: wave h produces output features 32 h .. 32 h + 31 for all tokens, weights straight from L2
-    const f16* res = (const f16*)p.res;
-    const long long rr = 2LL * p.ldres;
-    long long pix[4];
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi) pix[fi] = pixel(16 * fi + lr);
-    f16x4 rvh[2][4], rvl[2][4];
-    if (res) {   // shortcut: requested before the barrier, consumed after the projection
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const f16* rp = res + pix[fi] * rr + h * HD + 16 * f + 4 * lg;
-                rvh[f][fi] = *(const f16x4*)rp;
-                rvl[f][fi] = *(const f16x4*)(rp + p.ldres);
-            }
-    }
+#ifndef RS_ATTN_SPLIT_EARLYW
+    load_w((const f16*)p.wproj, h * HD, wfh, wfl);
+#endif
+    const bool has_res = p.res != nullptr;
     __syncthreads();   // all heads' attention results are in LDS
+    RS_ATTN_STAMP(9);
     f32x4 acc2[2][4];
     project(wfh, wfl, p.bproj, h * HD, acc2);
     float s1[2][4], s2[2][4];   // per-channel sums of the stored values (the pair reproduces v to 2^-23) over this lane's four tokens
@@ -310,18 +338,21 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
+            // cell of (token t, features c .. c + 3) in the residual / output tile: read and rewritten by this lane only
+            const int t = 16 * fi + lr, c = h * HD + 16 * f + 4 * lg;
+            char* cell = rt + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2;
             f16x4 hv, lv;
+            if (has_res) { hv = *(const f16x4*)cell; lv = *(const f16x4*)(cell + XS_PLANE); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                f16 a, c;
-                const float v = acc2[f][fi][r] + (res ? rs_join(rvh[f][fi][r], rvl[f][fi][r]) : 0.f);
-                rs_split(v, a, c);
-                hv[r] = a; lv[r] = c;
-                s1[f][r] += v; s2[f][r] = fmaf(v, v, s2[f][r]);
+                f16 a, c2;
+                const float v = acc2[f][fi][r] + (has_res ? rs_join(hv[r], lv[r]) : 0.f);
+                rs_split(v, a, c2);
+                hv[r] = a; lv[r] = c2;
+                if (p.ystats) { s1[f][r] += v; s2[f][r] = fmaf(v, v, s2[f][r]); }
             }
-            f16* dst = out + pix[fi] * ro + h * HD + 16 * f + 4 * lg;
-            *(f16x4*)dst = hv;
-            *(f16x4*)(dst + p.ldo) = lv;
+            *(f16x4*)cell = hv;
+            *(f16x4*)(cell + XS_PLANE) = lv;
         }
     if (p.ystats) {   // statistics for norm2: the wave holds its 32 features of all 64 tokens of the window
         float* dst = p.ystats + (((long long)b * (nwx * (H / WS)) + blockIdx.x) * p.ystats_ld + h * HD) * 2;
@@ -335,9 +366,38 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
                 if (lr == 0) { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
             }
     }
+    __syncthreads();   // the output tile is complete
+    // whole rows out: 2 planes x 24 pieces of 8 token rows x 128 B (8 full cache lines per wave instruction), 8 per wave
+    {
+        const int rsub = lane >> 3, ps = lane & 7, chunk = ps ^ (rsub & 7);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int it = h * 8 + q, plane = it / 24, r24 = it - plane * 24, st = r24 >> 3, grp = r24 & 7;
+            const f16x8 v = *(const f16x8*)(rt + plane * XS_PLANE + st * XS_STAGE + (grp * 8 + rsub) * 128 + ps * 16);
+            *(f16x8*)(out + pixel(grp * 8 + rsub) * ro + plane * p.ldo + st * 64 + chunk * 8) = v;
+        }
+    }
+    RS_ATTN_STAMP(10);
 }
 
 }  // namespace
+
+#ifdef RS_SPLIT_ABLATE
+extern "C" int rs_attn_split_phase_cycles(int nwg, int nst, double* out) {
+    static long long h[16 * 4096];
+    if (nwg < 1 || nwg > 4096 || nst < 2 || nst > 16) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attns_clk), sizeof(long long) * 16 * nwg) != hipSuccess) return -1;
+    for (int k = 0; k + 1 < nst; ++k) {
+        out[k] = 0.0;
+        for (int i = 0; i < nwg; ++i) out[k] += (double)(h[16 * i + k + 1] - h[16 * i + k]) / nwg;
+    }
+    long long lo = h[0], hi = h[nst - 1];   // span of the launch: first start .. last end over the stamped workgroups
+    for (int i = 0; i < nwg; ++i) { lo = h[16 * i] < lo ? h[16 * i] : lo; hi = h[16 * i + nst - 1] > hi ? h[16 * i + nst - 1] : hi; }
+    out[nst - 1] = (double)(hi - lo);
+    return 0;
+}
+#endif
 
 // fused qkv projection + window attention (+ output projection + shortcut) in split storage: 6 heads of 32; x / res / out are
 // split-storage NHWC tensors, wqkv / wproj split weight rows [K hi | K lo]
@@ -349,10 +409,14 @@ extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 4;
     if (xb >= 0xF0000000ull) return -2;
     const int nwin = (p.H / 8) * (p.W / 8);
-    const size_t lds = (size_t)2 * 3 * 64 * 128 + (size_t)p.heads * 2 * 32 * (64 + 8) * sizeof(f16);
+    const size_t rb = p.res ? (size_t)p.B * p.H * p.W * p.ldres * 4 : 0;
+    if (rb >= 0xF0000000ull || (p.wproj && p.res && (p.ldres % 8))) return -2;
+    // token tile (hi, lo) + V^T (hi, lo) + the bias table (+ with the fused projection the residual / output tile)
+    const size_t lds_max = (size_t)2 * 3 * 64 * 128 + (size_t)6 * 2 * 32 * (64 + 8) * sizeof(f16) + 5632 + (size_t)2 * 3 * 64 * 128;
+    const size_t lds = lds_max - (p.wproj ? 0 : (size_t)2 * 3 * 64 * 128);
     static bool attr_done[RS_MAX_DEVICES] = {};
     bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_set = true; }
+    hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

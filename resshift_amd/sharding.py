@@ -142,7 +142,7 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return _lib.window_copy(x, 0, 0, H + pad_h, W + pad_w)
 
 
-BLOB_CACHE_MAGIC = b"RSBLOB04"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+BLOB_CACHE_MAGIC = b"RSBLOB05"   # bump when the packed layout (csrc/engine.hip weight builder) changes
 
 
 def checkpoint_fingerprint(paths) -> bytes:
