@@ -8,6 +8,7 @@
 //              (swin_transformer.py:35-63,252-275) folded into the load/store addressing.
 //   Row softmax: ldm/modules/diffusionmodules/model.py:193 (AE mid-block attention).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -744,6 +745,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr3_t;
 __device__ __forceinline__ void lds_dma16_na(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr3_t)lds, 16, voff, 0, 0, 0);
 }
+// per-lane byte offset + wave-uniform byte offset (the instruction's scalar offset operand: no VGPR arithmetic for the uniform part)
+__device__ __forceinline__ void lds_dma16_vs(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr3_t)lds, 16, voff, (int)soff, 0, 0);
+}
 
 // Window attention with the qkv projection fused in (fp16 storage, E = 32 * heads <= 192, heads = 6 in every shipped config):
 // one workgroup per window, one wave per head.  The window's 64 normalised tokens are gathered (roll + partition folded
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     for (int e = tid; e < 6 * 225; e += 384) {
         const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
         const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
-        btab[e] = p.bias_n[(hh * NT + i) * NT + j];
+        btab[e] = p.bias_n[(hh * NT + i) * NT + j] * 1.44269504088896f;   // in units of log2: the softmax below works in base 2
     }
     auto win_y = [&](int w) { return (int)(blockIdx.x * NW + w) / nwx; };
     auto pixel = [&](int w, int t) -> long long {
@@ -799,29 +804,24 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
         int sx = wx * WS + (t & 7) + p.shift; if (sx >= p.W) sx -= p.W;
         return ((long long)b * p.H + sy) * p.W + sx;
     };
-    // ---- tokens of the windows -> LDS: per window 8 row groups x 3 K stages = 24 LDS-DMA instructions, 4 per wave
+    // ---- tokens of the windows -> LDS: per window 8 row groups x 3 K stages = 24 LDS-DMA instructions, 4 per wave.  A piece is 8 tokens of
+    // one window row x 64 channels: the row (and the stage) is wave-uniform -> scalar offset; the column and the chunk are the lane's
+    auto dma_tile = [&](const __amdgpu_buffer_rsrc_t r, int ld, char* dst, int w) {
+        const int wi = blockIdx.x * NW + w, wy = wi / nwx, wx = wi - wy * nwx;
+        const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
+        int sx = wx * WS + rsub + p.shift; if (sx >= p.W) sx -= p.W;
+        const unsigned voff = (unsigned)(sx * ld + kcp * 8) * 2u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int it = h * 4 + q, st = it >> 3, grp = it & 7;
+            int sy = wy * WS + grp + p.shift; if (sy >= p.H) sy -= p.H;
+            lds_dma16_vs(r, dst + st * XS_STAGE + (grp * 8) * 128, voff, (unsigned)(((b * p.H + sy) * p.W) * ld + st * 64) * 2u);
+        }
+    };
     {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
-        const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int it = h * 4 + q, st = it >> 3, grp = it & 7;
-                const unsigned off = (unsigned)(pixel(w, grp * 8 + rsub) * p.ldx + st * 64 + kcp * 8) * 2u;
-                lds_dma16_na(rx, smem + w * XS_WIN + st * XS_STAGE + (grp * 8) * 128, off);
-            }
-        if (p.wproj && p.res) {   // the shortcut's rows: in flight until the projection epilogue
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int it = h * 4 + q, st = it >> 3, grp = it & 7;
-                    const unsigned off = (unsigned)(pixel(w, grp * 8 + rsub) * p.ldres + st * 64 + kcp * 8) * 2u;
-                    lds_dma16_na(rr, rt_of(w) + st * XS_STAGE + (grp * 8) * 128, off);
-                }
-        }
+        for (int w = 0; w < NW; ++w) dma_tile(rx, p.ldx, smem + w * XS_WIN, w);
     }
     const f16* wq = (const f16*)p.wqkv;
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
@@ -917,6 +917,13 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
                     for (int r = 0; r < 4; ++r) vt[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = (f16)acc[f][ft][r];
         }
     }
+    if (p.wproj && p.res) {
+        // the shortcut's rows -> the residual / output tiles by LDS-DMA, requested HERE: memory operations complete in order, so the next
+        // wait (the projection weights, behind the attention) is the first that includes them - they travel during the whole attention
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dma_tile(rr, p.ldres, rt_of(w), w);
+    }
     RS_ATTN_STAMP(5);
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tiles (they are overwritten below)
     RS_ATTN_STAMP(6);
@@ -932,48 +939,52 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
                 s[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[w][fj], qf[w][fi], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
-        if (p.shift > 0) {
-            const int wy = win_y(w);
-            auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
-            rid_i = band(lr & 7);
+        // softmax over the keys (per query column i = 16 fi + lr) in base 2: the scores arrive as s * (scale log2 e) + (bias log2 e) (the
+        // table is stored pre-multiplied), so the exponential is the bare v_exp_f32.  The row sums come out of the P V matrix product (a
+        // row of ones appended to V^T, below).  Only windows of the LAST window row can carry the shift mask (the mask regions are bands
+        // of window_row * 8 + token_column, see win_attn_kernel): every other window takes the mask-free path (a wave-uniform branch).
+        const float c2 = p.scale * 1.44269504088896f;
+        const bool masked = p.shift > 0 && win_y(w) == p.H / WS - 1;
+        auto softmax = [&](auto MK) {
+            constexpr bool MASK = decltype(MK)::value;
+            int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+            if constexpr (MASK) {
+                const int wy = win_y(w);
+                auto band = [&](int c) { const int yq = wy * WS + c; return yq < p.H - WS ? 0 : (yq < p.H - p.shift ? 1 : 2); };
+                rid_i = band(lr & 7);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
-        }
-        float inv[4];
+                for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
+            }
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaf(s[fj][fi][r], c2, tb[30 * (fi - fj) - r]);
+                        if constexpr (MASK) { if (rid_j[r] != rid_i) v += -100.0f * 1.44269504088896f; }
+                        s[fj][fi][r] = v;
+                        m = fmaxf(m, v);
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[fj][fi][r] = __builtin_amdgcn_exp2f(s[fj][fi][r] - m);
+            }
+        };
+        if (masked) softmax(std::true_type{}); else softmax(std::false_type{});
+        f32x4 o[2][4], ol[4];    // [fd][fi]; ol: the row of ones -> sum over the keys of the fp16 probabilities, for every lane of column i
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
-            float m = -3.0e38f;
+            ol[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(s[fj][fi][r], p.scale, tb[30 * (fi - fj) - r]);
-                    if (p.shift > 0 && rid_j[r] != rid_i) v += -100.0f;
-                    s[fj][fi][r] = v;
-                    m = fmaxf(m, v);
-                }
-            }
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float l = 0.f;
-#pragma unroll
-            for (int fj = 0; fj < 4; ++fj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[fj][fi][r] - m);
-                    s[fj][fi][r] = e;
-                    l += e;
-                }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            inv[fi] = 1.0f / l;
+            for (int fd = 0; fd < 2; ++fd) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 o[2][4];    // [fd][fi]
-#pragma unroll
-        for (int fd = 0; fd < 2; ++fd)
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi) o[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f16x8 ones = f16x8{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
         const f16* vt = vt_of(w);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -993,19 +1004,23 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
             for (int fd = 0; fd < 2; ++fd)
 #pragma unroll
                 for (int fi = 0; fi < 4; ++fi) o[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[fd], pb[fi], o[fd][fi], 0, 0, 0);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) ol[fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pb[fi], ol[fi], 0, 0, 0);
         }
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
+        for (int fi = 0; fi < 4; ++fi) {
+            const float inv = 1.0f / ol[fi][0];
 #pragma unroll
             for (int fd = 0; fd < 2; ++fd) {
                 f16x4 hv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv[fi]);
+                for (int r = 0; r < 4; ++r) hv[r] = (f16)(o[fd][fi][r] * inv);
                 const int t = 16 * fi + lr, c = h * HD + 16 * fd + 4 * lg;     // token row, feature
                 if (!p.wproj) *(f16x4*)(out + pixel(w, t) * p.ldo + c) = hv;
                 // fused output projection: the heads' results meet in LDS (the token tile's space, same row / swizzle format)
                 else *(f16x4*)(smem + w * XS_WIN + (c >> 6) * XS_STAGE + t * 128 + ((((c & 63) >> 3) ^ (t & 7)) << 4) + (c & 7) * 2) = hv;
             }
+        }
         RS_ATTN_STAMP(7 + w);
     }
     if (!p.wproj) return;

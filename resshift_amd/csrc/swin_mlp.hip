@@ -46,6 +46,13 @@ __device__ __forceinline__ void mlp_stats(const f32x4 (&o)[FC2][2], float* ystat
         }
 }
 
+#ifdef RS_SPLIT_ABLATE
+__device__ long long g_mlp_clk[8 * 4096];   // phase stamps of wave 0 of the first 4096 workgroups (fp16 and split kernels share it)
+#define RS_MLP_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0 && blockIdx.x < 4096) g_mlp_clk[8 * blockIdx.x + (k)] = clock64(); } while (0)
+#else
+#define RS_MLP_STAMP(k)
+#endif
+
 struct MlpParams {
     const f16* x; const f16* w1; const float* b1; const f16* w2; const float* b2; const f16* res; f16* y;
     int M, ldx, ldres, ldy;
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int i = 0; i < E / 64; ++i) lds_dma16(r2, b2 + (64 * i) * 128, ((unsigned)(64 * i + rr) * HD + (unsigned)(hc * HC + kcp * 8)) * 2u);
     };
+    RS_MLP_STAMP(0);
     issue_w(0, 0);
     issue_w(1, 1);
 
@@ -103,6 +111,19 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         const f16* xr = p.x + (long long)m * p.ldx + lg * 8;
 #pragma unroll
         for (int ks = 0; ks < 2 * KS1; ++ks) xf[ks][j] = *(const f16x8*)(xr + ks * 32);
+    }
+    // the shortcut of this wave's output tile (lane: 4 channels of 2 tokens per channel fragment), requested with the tokens and consumed
+    // in the epilogue: fetched there it was an exposed burst of twelve half-used-line loads per wave (8 k of a workgroup's 70 k cycles,
+    // profiles/r3_attn_phases.txt); 24 registers for the length of the kernel
+    const bool res_ok = p.res != nullptr;
+    f16x4 rv[FC2][2];
+    if (res_ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres;
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) rv[i][j] = *(const f16x4*)(p.res + mr + wc * (E / 2) + i * 16 + lg * 4);
+        }
     }
     if (p.xcoef) {   // GroupNorm (norm2) folded in, rounded to fp16 exactly where the separate apply kernel rounds
         const float* sc = p.xcoef + (long long)(m0 / p.HW) * 2 * E;
@@ -131,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     for (int i = 0; i < FC2; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     int slot = 0;
+    RS_MLP_STAMP(1);
     for (int hc = 0; hc < NHC; ++hc) {
         // chunk hc has landed once only the younger loads may be outstanding: the bias pair and the LW DMA instructions of
         // chunk hc+1 (issued one iteration ago, in that order); the tail iterations simply drain everything
@@ -195,22 +217,17 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         }
         bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
         slot = slot + 1 == NSL ? 0 : slot + 1;
+#ifdef RS_SPLIT_ABLATE
+        if (hc == 0) RS_MLP_STAMP(2);
+#endif
     }
+    RS_MLP_STAMP(3);
     __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
+    RS_MLP_STAMP(4);
 
     // ---- epilogue: + b2 + residual -> fp16 -> transposition through LDS -> 16-byte NHWC stores
     constexpr int ROWB = (E / 2) * 2 + 16;
     char* stg = smem + wave * 32 * ROWB;
-    const bool res_ok = p.res != nullptr;
-    f16x4 rv[FC2][2];
-    if (res_ok) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres;
-#pragma unroll
-            for (int i = 0; i < FC2; ++i) rv[i][j] = *(const f16x4*)(p.res + mr + wc * (E / 2) + i * 16 + lg * 4);
-        }
-    }
 #pragma unroll
     for (int i = 0; i < FC2; ++i) {
         const int n = wc * (E / 2) + i * 16 + lg * 4;
@@ -231,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     }
     if (p.ystats && m0 + wp * 32 < p.M) mlp_stats<FC2>(o, p.ystats, p.ystats_ld, m0 + wp * 32, p.HW, wc * (E / 2), lr, lg);
     RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
+    RS_MLP_STAMP(5);
     constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
     for (int idx = lane; idx < NITEM; idx += 64) {
         const int row = idx / CPR, c8 = idx - row * CPR;
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
         if (m >= p.M) continue;
         *(uint4*)(p.y + (long long)m * p.ldy + wc * (E / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
     }
+    RS_MLP_STAMP(6);
 }
 
 }  // namespace
@@ -329,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
             lds_dma16(r2, smem + W2R + slot * W2_SLOT + piece * 1024, (n * (unsigned)(2 * HD) + plane * (unsigned)HD + (unsigned)(t * HS) + sub) * 2u);
         }
     };
+    RS_MLP_STAMP(0);
     issue_w(0, 0);
 
     // token fragments (MFMA B operand), hi and lo, straight from global memory: lane (lr, lg) holds channels 32 c + 8 lg .. of token lr
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
 #pragma unroll
     for (int i = 0; i < FC2; ++i) { o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    RS_MLP_STAMP(1);
     for (int t = 0; t < NST; ++t) {
         const int slot = t & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t have landed
@@ -418,8 +439,13 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
                 }
             }
         }
+#ifdef RS_SPLIT_ABLATE
+        if (t == 0) RS_MLP_STAMP(2);
+#endif
     }
+    RS_MLP_STAMP(3);
     __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
+    RS_MLP_STAMP(4);
 
     // ---- epilogue: 2^-11 O + b2 + residual, then the hi and the lo halves through LDS into 16-byte stores
     constexpr int ROWB = (E / 2) * 2 + 16;
@@ -454,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         }
     }
     if (p.ystats && m0 + wp * 32 < p.M) mlp_stats<FC2>(o, p.ystats, p.ystats_ld, m0 + wp * 32, p.HW, wc * (E / 2), lr, lg);
+    RS_MLP_STAMP(5);
     constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -475,9 +502,25 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         }
         RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
     }
+    RS_MLP_STAMP(6);
 }
 
 }  // namespace
+
+#ifdef RS_SPLIT_ABLATE
+// ablate builds: mean cycles between consecutive stamps 0 .. 6 of wave 0 over the first `nwg` workgroups of the last fused-MLP launch
+extern "C" int rs_mlp_phase_cycles(int nwg, double* out6) {
+    static long long h[8 * 4096];
+    if (nwg < 1 || nwg > 4096) return -1;
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_clk), sizeof(long long) * 8 * nwg) != hipSuccess) return -1;
+    for (int k = 0; k < 6; ++k) {
+        out6[k] = 0.0;
+        for (int i = 0; i < nwg; ++i) out6[k] += (double)(h[8 * i + k + 1] - h[8 * i + k]) / nwg;
+    }
+    return 0;
+}
+#endif
 
 // split storage: x / res / y tensors of (hi, lo) pairs, w1 / w2 packed [rows][K hi | K lo]
 extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,

@@ -16,6 +16,7 @@
 //   4. the heads' results meet in LDS (the token tile's space, same format) and wave h produces output features 32h .. 32h + 31 of
 //      the projection, adds the shortcut and stores the (hi, lo) pair.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     for (int e = tid; e < 6 * 225; e += 384) {
         const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
         const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
-        btab[e] = p.bias_n[(hh * NT + i) * NT + j];
+        btab[e] = p.bias_n[(hh * NT + i) * NT + j] * 1.44269504088896f;   // in units of log2: the softmax below works in base 2
     }
     const int shift = p.shift, H = p.H, W = p.W;
     auto pixel = [&](int t) -> long long {
@@ -74,15 +75,6 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             // pixel record [ldx halfs hi | ldx halfs lo]
             const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldx * 2 + plane * p.ldx + st * 64 + kcp * 8) * 2u;
             lds_dma16_ws(rx, smem + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
-        }
-        if (p.wproj && p.res) {   // the shortcut's rows: in flight until the projection epilogue
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int it = h * 8 + q, plane = it / 24, r24 = it - plane * 24, st = r24 >> 3, grp = r24 & 7;
-                const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldres * 2 + plane * p.ldres + st * 64 + kcp * 8) * 2u;
-                lds_dma16_ws(rr, rt + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
-            }
         }
     }
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
@@ -148,8 +140,8 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     };
     const f16* wq = (const f16*)p.wqkv;
     f16x8 wfh[2][KS], wfl[2][KS];
-    load_w(wq, h * HD, wfh, wfl);     // q_h weights: requested together with the token tile, one L2 round trip for both
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_w(wq, h * HD, wfh, wfl);     // q_h weights: requested together with the token tile ...
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // ... but only the tile (8 LDS-DMA instructions, older than the 24 weight loads) is waited for here
     __syncthreads();   // the window's tokens are in LDS
     RS_ATTN_STAMP(1);
     if (p.xcoef) {
@@ -209,6 +201,18 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     RS_ATTN_STAMP(5);
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tile (it is overwritten below)
     RS_ATTN_STAMP(6);
+    if (p.wproj && p.res) {
+        // the shortcut's rows -> the residual / output tile by LDS-DMA, requested HERE: memory operations complete in order, so the next
+        // wait (the projection weights, behind the attention) is the first that includes them - they travel during the whole attention
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, res_bytes, 0x00020000);
+        const int rsub = lane >> 3, kcp = (lane & 7) ^ (rsub & 7);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int it = h * 8 + q, plane = it / 24, r24 = it - plane * 24, st = r24 >> 3, grp = r24 & 7;
+            const unsigned off = (unsigned)(pixel(grp * 8 + rsub) * p.ldres * 2 + plane * p.ldres + st * 64 + kcp * 8) * 2u;
+            lds_dma16_ws(rr, rt + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
+        }
+    }
     f32x4 s[4][4];  // [fj][fi]
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj)
@@ -220,51 +224,56 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[fj][fi][r] = fmaf(c[r], RS_LO_INV, m[r]);
         }
-    int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
-    if (shift > 0) {   // region ids of the (quirky) shift mask: band of window_row*8 + token_column (see win_attn_kernel)
-        auto band = [&](int c) { const int yq = wy * WS + c; return yq < H - WS ? 0 : (yq < H - shift ? 1 : 2); };
-        rid_i = band(lr & 7);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
-    }
-    float inv[4];
+    // softmax over the keys (per query column i = 16 fi + lr) in base 2, fp32: the scores become s * (scale log2 e) + (bias log2 e) (the table
+    // is stored pre-multiplied) and the exponential is the bare v_exp_f32 (1 ulp; expf's range reduction bought nothing here: the arguments
+    // are <= 0 and the result is split to 22 bits right after).  The row sums come out of the P V matrix product (a row of ones appended to
+    // V^T, below).  Only windows of the LAST window row can carry the shift mask (bands of window_row * 8 + token_column, see
+    // win_attn_kernel): every other window takes the mask-free path (a wave-uniform branch).
+    const float c2 = p.scale * 1.44269504088896f;
     // bias of (i = 16 fi + lr, j = 16 fj + 4 lg + r) = tb[30 (fi - fj) - r]
     const float* tb = btab + h * 225 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
+    auto softmax = [&](auto MK) {
+        constexpr bool MASK = decltype(MK)::value;
+        int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
+        if constexpr (MASK) {   // region ids of the (quirky) shift mask: band of window_row*8 + token_column (see win_attn_kernel)
+            auto band = [&](int c) { const int yq = wy * WS + c; return yq < H - WS ? 0 : (yq < H - shift ? 1 : 2); };
+            rid_i = band(lr & 7);
 #pragma unroll
-    for (int fi = 0; fi < 4; ++fi) {
-        __builtin_amdgcn_sched_barrier(0);   // one query fragment's 16 table reads at a time (all 64 up front do not fit 256 registers)
-        float m = -3.0e38f;
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaf(s[fj][fi][r], p.scale, tb[30 * (fi - fj) - r]);
-                if (shift > 0 && rid_j[r] != rid_i) v += -100.0f;
-                s[fj][fi][r] = v;
-                m = fmaxf(m, v);
-            }
+            for (int r = 0; r < 4; ++r) rid_j[r] = band(4 * (lg & 1) + r);
         }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f;
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
+        for (int fi = 0; fi < 4; ++fi) {
+            __builtin_amdgcn_sched_barrier(0);   // one query fragment's 16 table reads at a time (all 64 up front do not fit 256 registers)
+            float m = -3.0e38f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = expf(s[fj][fi][r] - m);
-                s[fj][fi][r] = e;
-                l += e;
+            for (int fj = 0; fj < 4; ++fj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaf(s[fj][fi][r], c2, tb[30 * (fi - fj) - r]);
+                    if constexpr (MASK) { if (rid_j[r] != rid_i) v += -100.0f * 1.44269504088896f; }
+                    s[fj][fi][r] = v;
+                    m = fmaxf(m, v);
+                }
             }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        inv[fi] = 1.0f / l;
-    }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[fj][fi][r] = __builtin_amdgcn_exp2f(s[fj][fi][r] - m);
+        }
+    };
+    if (shift > 0 && wy == H / WS - 1) softmax(std::true_type{}); else softmax(std::false_type{});
     RS_ATTN_STAMP(7);   // scores + softmax done
     f32x4 om[2][4], oc[2][4];    // [fd][fi] main / cross
+    f32x4 lm[4], lc[4];          // the row of ones: sum over the keys of P's hi / lo parts, for every lane of column i
+    const f16x8 ones = f16x8{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
 #pragma unroll
-    for (int fd = 0; fd < 2; ++fd)
+    for (int fi = 0; fi < 4; ++fi) {
+        lm[fi] = f32x4{0.f, 0.f, 0.f, 0.f}; lc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi) { om[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int fd = 0; fd < 2; ++fd) { om[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[fd][fi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         f16x8 vah[2], val[2], pbh[4], pbl[4];
@@ -292,7 +301,15 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
                 oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vah[fd], pbl[fi], oc[fd][fi], 0, 0, 0);
                 oc[fd][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(val[fd], pbh[fi], oc[fd][fi], 0, 0, 0);
             }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            lm[fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pbh[fi], lm[fi], 0, 0, 0);
+            lc[fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pbl[fi], lc[fi], 0, 0, 0);
+        }
     }
+    float inv[4];
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) inv[fi] = 1.0f / fmaf(lc[fi][0], RS_LO_INV, lm[fi][0]);
     f16* out = (f16*)p.out;
     const long long ro = 2LL * p.ldo;   // output pixel record [ldo hi | ldo lo]
 #pragma unroll

@@ -23,6 +23,21 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 print(f"split fused mlp M={M}: {ms*1e3:.1f} us  {4.0*M*E*HD/ms/1e9:.1f} TFLOP/s (x3 MFMA: {12.0*M*E*HD/ms/1e9:.1f})")
 
+
+def phases(tag):
+    """ablate builds: wave 0's phase stamps of the last launch (mean over the first 1024 workgroups)"""
+    import ctypes
+    f = getattr(lib, "rs_mlp_phase_cycles", None)
+    if f is None:
+        return
+    out = (ctypes.c_double * 6)()
+    if f(ctypes.c_int(min(1024, M // 128)), out) == 0:
+        names = ["prologue (weight DMA issue, token fragments, GN fold)", "first step", "steps 1 .. n-1", "barrier", "b2 + residual (+ statistics)", "split / staging / stores"]
+        print(f"  {tag} phases: " + "  ".join(f"{n}: {out[i]:.0f}" for i, n in enumerate(names)) + f"   total {sum(out):.0f}")
+
+
+phases("split")
+
 # fp16 fused kernel on the same shape for comparison
 xh = x.to(gpu, torch.float16)
 w1h, w2h = w1.to(gpu, torch.float16), w2.to(gpu, torch.float16)
@@ -35,3 +50,4 @@ for _ in range(20):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 print(f"fp16 fused mlp M={M}: {ms*1e3:.1f} us  {4.0*M*E*HD/ms/1e9:.1f} TFLOP/s")
+phases("fp16")
