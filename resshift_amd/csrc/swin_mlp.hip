@@ -101,7 +101,6 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     };
     RS_MLP_STAMP(0);
     issue_w(0, 0);
-    issue_w(1, 1);
 
     // token fragments (MFMA B operand: lane (lr, lg) holds 8 consecutive K values of token row lr): straight from global memory
     f16x8 xf[2 * KS1][2];
@@ -145,6 +144,9 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     f32x4 bcur[2], bnxt[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { bcur[i] = *(const f32x4*)(p.b1 + wc * 32 + i * 16 + lg * 4); bnxt[i] = bcur[i]; }
+    // chunk 1 is requested LAST: the first iteration's counted wait (all but the youngest LW + 2 operations) then covers chunk 0, the
+    // tokens and the shortcut but not chunk 1 - the order every later iteration has (bias pair, then the chunk two ahead)
+    issue_w(1, 1);
 
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};   // k-step 0 / 1 inside a 128-byte stage
     f32x4 o[FC2][2];
