@@ -116,7 +116,8 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
     if (in_dt != out_dt || nz != 1 || p.C1 != 0) return 0;
     if (!((in_dt == RS_F16 && (on & 1)) || (in_dt == RS_F16S && (on & 2)))) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
-    if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && (p.ldres % 4))) return 0;
+    // (fp16 storage fetches the residual as 16-byte row pieces: 8-channel alignment of its stride and of its base)
+    if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && ((p.ldres % 8) || ((size_t)p.res & 15)))) return 0;
     auto waste = [&](int bc) { return ((p.Cout + bc - 1) / bc) * bc - p.Cout; };
     int best = 128, bw = waste(128);
     if (waste(160) < bw) { best = 160; bw = waste(160); }

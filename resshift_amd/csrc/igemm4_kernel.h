@@ -581,6 +581,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     } else {
         auto run = [&](auto res_tag) __attribute__((always_inline)) {
         constexpr bool RES = decltype(res_tag)::value;
+#ifdef RS_IG4_RES_FRAGS   // (A/B: the residual in accumulator layout, 8 B per lane = 16 quarter-used cache lines per wave instruction)
         f16x4 rv[FC][FP];   // the residual of the whole wave tile, all loads in flight together
         if constexpr (RES) {
 #pragma unroll
@@ -591,6 +592,30 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             }
         }
         __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+#else
+        // The residual of the wave tile as ROWS: 16 B per lane with the store loop's addressing (a pixel's BC / 2 channels are
+        // contiguous), requested in front of the barrier, parked in the wave-private staging tile behind it and added from there.  In
+        // accumulator layout (8 B per lane, 16 pixels x 32 B per instruction) the same data cost 4 x the cache-line look-ups: the
+        // epilogue was 14 - 16 k cycles with a residual, 6 k without (profiles/r3_igemm4_phases.txt, r3_attn_phases.txt).
+        uint4 rq[CPR];
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                const int idx = lane + 64 * k, row = idx / CPR, c8 = idx - row * CPR;
+                const int n = n0 + wc * (BC / 2) + c8 * 8;
+                rq[k] = n < p.Cout ? *(const uint4*)(res + pixel(row) * p.ldres + n) : uint4{0u, 0u, 0u, 0u};
+            }
+        }
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                const int idx = lane + 64 * k, row = idx / CPR, c8 = idx - row * CPR;
+                *(uint4*)(stg + row * ROWB + c8 * 16) = rq[k];
+            }
+            RS_STAGING_SYNC();   // wave-private tile: the wave's own LDS order suffices
+        }
+#endif
         auto finish = [&](auto act_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -601,13 +626,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                     f32x4 v = acc[i][j] * p.out_scale + bvs[i];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs_act_t<ACT, true>(v[r]);
+                    f16x4* const cell = (f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2);   // read and rewritten by this lane only
                     if constexpr (RES) {
+#ifdef RS_IG4_RES_FRAGS
+                        const f16x4 rr = rv[i][j];
+#else
+                        const f16x4 rr = *cell;
+#endif
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
                     }
                     f16x4 h;
                     h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)v[3];
-                    *(f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2) = h;
+                    *cell = h;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float f = (float)h[r]; s1[r] += f; s2[r] = fmaf(f, f, s2[r]); }   // of the STORED value
                     __builtin_amdgcn_sched_barrier(0);
