@@ -45,7 +45,7 @@ def _compile(src: str) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    stamp = os.path.join(OBJ, "stamp.txt")
+    stamp = LIB + ".stamp"   # beside the library: the object directory does not travel to the GPU box (.gpurunignore)
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
