@@ -176,9 +176,8 @@ __global__ __launch_bounds__(512, 2) void ae_flash_attn_kernel(FlashParams p) {
 template <int C>
 int launch_flash(const FlashParams& p, int nz, hipStream_t st) {
     constexpr size_t lds = (size_t)(C / 64) * 64 * 128 + (size_t)C * 128;
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)ae_flash_attn_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) { (void)hipFuncSetAttribute((const void*)ae_flash_attn_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
     hipLaunchKernelGGL((ae_flash_attn_kernel<C>), dim3(p.T / 128, nz), dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -54,7 +54,13 @@ template <> __device__ __forceinline__ void rs_st<h2s>(h2s* p, int lo, float v) 
 // per-device "function attribute already set" flags of the launchers (hipFuncSetAttribute is per device: a process that drives
 // several GPUs must set the dynamic-LDS limit on each of them)
 #define RS_MAX_DEVICES 64
-static inline int rs_device_slot() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < RS_MAX_DEVICES ? d : 0; }
+// (a device index outside the table, or a failing hipGetDevice, gets the spare slot RS_MAX_DEVICES, whose flag the launchers never keep
+// set: such a device pays the hipFuncSetAttribute call on every launch instead of silently inheriting device 0's flag)
+static inline int rs_device_slot() { int d = -1; if (hipGetDevice(&d) != hipSuccess) d = -1; return d >= 0 && d < RS_MAX_DEVICES ? d : RS_MAX_DEVICES; }
+struct RsAttrFlags {   // "hipFuncSetAttribute done on this device?" of one kernel instantiation; true = the caller must set it now
+    bool done[RS_MAX_DEVICES] = {};
+    bool need() { const int s = rs_device_slot(); if (s >= RS_MAX_DEVICES) return true; if (done[s]) return false; done[s] = true; return true; }
+};
 
 // Between a wave's writes to ITS OWN epilogue staging tile and its reads of that tile (and before the tile is overwritten) the wave's own
 // LDS instruction order is all that is needed: a workgroup barrier there makes every wave wait for the slowest one four times per

@@ -334,11 +334,9 @@ hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     dim3 grid(tiles, 1, p.splitk > 1 ? p.splitk : nz);
     const size_t lds = 2 * (BP + BC) * 128;
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<TI, TO, BP, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((igemm_kernel<TI, TO, BP, BC>), grid, dim3(256), lds, st, p);
     if (p.splitk > 1) {

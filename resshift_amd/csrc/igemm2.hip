@@ -411,11 +411,9 @@ hipError_t launch2_cfg(IGemmParams p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)NS * (BP + BCP) * 128;
     static_assert(NS * (BP + BCP) * 128 <= 160 * 1024, "LDS");
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)igemm2_kernel<TI, TO, BP, BC, NS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const size_t esz = sizeof(TI);
     const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * esz, wb = (size_t)p.Cout * p.Ktot * esz;

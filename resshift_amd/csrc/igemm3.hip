@@ -321,11 +321,9 @@ template <typename TO, int BC>
 hipError_t launch3_cfg(IGemmParams p, hipStream_t st) {
     const int tiles = ((p.M + 255) / 256) * ((p.Cout + BC - 1) / BC);
     const size_t lds = (size_t)3 * (256 + BC) * 128;
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)igemm3_kernel<TO, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * 2, wb = (size_t)p.Cout * p.Ktot * 2;
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets

@@ -116,8 +116,10 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
     if (in_dt != out_dt || nz != 1 || p.C1 != 0) return 0;
     if (!((in_dt == RS_F16 && (on & 1)) || (in_dt == RS_F16S && (on & 2)))) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
-    // (fp16 storage fetches the residual as 16-byte row pieces: 8-channel alignment of its stride and of its base)
-    if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && ((p.ldres % 8) || ((size_t)p.res & 15)))) return 0;
+    // (fp16 storage fetches the residual as 16-byte row pieces: 8-channel alignment of its stride; the BASE alignment is checked at launch -
+    // eligibility must be a function of the layout alone, never of a pointer value: the engine asks this planner in its dry sizing pass, in
+    // want_stats and again at launch, and the three answers have to agree)
+    if ((p.C0 % 32) || (p.ld0 % 8) || (p.Cout % 8) || (p.ldy % 8) || (p.res && (p.ldres % 8))) return 0;
     auto waste = [&](int bc) { return ((p.Cout + bc - 1) / bc) * bc - p.Cout; };
     int best = 128, bw = waste(128);
     if (waste(160) < bw) { best = 160; bw = waste(160); }
@@ -171,6 +173,7 @@ extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC
     int tw = 0, bc = 0, seg = 0, sk = 1;
     if (!rs_igemm4_plan(pp, in_dt, in_dt, 1, &tw, &bc, &seg, &sk) || tw != TW || bc != BC || (pp->splitk > 1 ? pp->splitk : 1) != sk) return -2;
     if (sk > 1 && !pp->partial) return -2;
+    if (((size_t)pp->x0 & 15) || ((size_t)pp->y & 15) || ((size_t)pp->res & 15)) return -2;   // 16-byte row pieces: a view whose channel offset is not a multiple of 8
     IGemmParams p = *pp;
     float* const want_stats = p.ystats;
     if (sk > 1) p.ystats = nullptr;   // slices cannot see the final values: the reduce kernel produces the statistics

@@ -692,11 +692,9 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     constexpr size_t lds = NXB * xbuf + ((NXB * xbuf + 3 * BC * 128 <= cap) ? 3 : 2) * (size_t)BC * 128;   // (NSLOT of the kernel)
     const int tiles = (SEG == 8 ? p.B / 4 : SEG == 16 ? p.B : p.B * (p.Ho / TH) * (p.Wo / TW)) * ((p.Cout + BC - 1) / BC);
     const int sk = p.splitk > 1 ? p.splitk : 1;
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const size_t esz = SPLIT ? 4 : 2;
     const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * esz, wb = (size_t)p.Cout * p.Ktot * esz;

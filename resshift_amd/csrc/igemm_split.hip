@@ -459,11 +459,9 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     constexpr size_t lds = (size_t)2 * 2 * (BP + BC) * 128;
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)igemm_split_kernel<TO, BP, BC, NWV, PIPE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const size_t xb = (size_t)p.B * p.Hs * p.Ws * p.ld0 * 4, wb = (size_t)p.Cout * p.Ktot * 4;
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets

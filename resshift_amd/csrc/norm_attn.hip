@@ -1133,13 +1133,11 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     }
 #endif
     {   // dynamic LDS above 64 KB needs the attribute: set once per device to the largest layout (fused projection)
-        static bool attr_done[RS_MAX_DEVICES] = {};
-        bool& attr_set = attr_done[rs_device_slot()];
-        if (!attr_set) {
+        static RsAttrFlags attr_flags;
+        if (attr_flags.need()) {
             const int per_win = 3 * 64 * 128 + 6 * 32 * (64 + 8) * 2 + 3 * 64 * 128;
             (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * per_win + 5632);
             (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, per_win + 5632);
-            attr_set = true;
         }
     }
     if (NW == 2) hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_kernel(MlpParams p) {
     for (int i = 0; i < 2; ++i) { bcur[i] = *(const f32x4*)(p.b1 + wc * 32 + i * 16 + lg * 4); bnxt[i] = bcur[i]; }
     // chunk 1 is requested LAST: the first iteration's counted wait (all but the youngest LW + 2 operations) then covers chunk 0, the
     // tokens and the shortcut but not chunk 1 - the order every later iteration has (bias pair, then the chunk two ahead)
+    __builtin_amdgcn_sched_barrier(0);   // (pins "bias pair, then chunk 1" as the youngest LW + 2 operations the counted wait below leaves in flight)
     issue_w(1, 1);
 
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};   // k-step 0 / 1 inside a 128-byte stage
@@ -276,11 +277,9 @@ extern "C" int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
     p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW; p.ystats = ystats; p.ystats_ld = ystats_ld;
     constexpr int LDS = 160 * 1024;
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)swin_mlp_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((swin_mlp_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -535,11 +534,9 @@ extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const flo
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
     p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW; p.ystats = ystats; p.ystats_ld = ystats_ld;
     constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) {
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)swin_mlp_split_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     hipLaunchKernelGGL((swin_mlp_split_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             lds_dma16_ws(rx, smem + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
         }
     }
+    // the hand-counted vmcnt(24) below assumes the 8 token DMAs are OLDER than the 24 q-weight loads: pin that order (ae_attn.hip does the same)
+    __builtin_amdgcn_sched_barrier(0);
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
     // one projection pass over the token tile: 32 output features starting at weight row n0 (rows [K hi | K lo], K = E) ->
     // acc[2 feature frags][4 token frags], final values (bias added, 2^-11 applied)
@@ -431,9 +433,8 @@ extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t
     // token tile (hi, lo) + V^T (hi, lo) + the bias table (+ with the fused projection the residual / output tile)
     const size_t lds_max = (size_t)2 * 3 * 64 * 128 + (size_t)6 * 2 * 32 * (64 + 8) * sizeof(f16) + 5632 + (size_t)2 * 3 * 64 * 128;
     const size_t lds = lds_max - (p.wproj ? 0 : (size_t)2 * 3 * 64 * 128);
-    static bool attr_done[RS_MAX_DEVICES] = {};
-    bool& attr_set = attr_done[rs_device_slot()];
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_set = true; }
+    static RsAttrFlags attr_flags;
+    if (attr_flags.need()) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); }
     hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

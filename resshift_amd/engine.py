@@ -287,7 +287,6 @@ class Engine:
 
     def profile_families(self):
         """per kernel family of the MFMA path: [(name, algorithmic FLOPs, kernel ms, launches)] of the last native call"""
-        out = (C.c_double * 3 * len(self.FAMILIES))()
         out = (C.c_double * (3 * len(self.FAMILIES)))()
         n = self.lib.rs_profile_families(self._h, out, 3 * len(self.FAMILIES))
         return [(self.FAMILIES[f], out[3 * f], out[3 * f + 1], int(out[3 * f + 2])) for f in range(max(0, n))]
