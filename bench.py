@@ -17,15 +17,21 @@ ranks-share-a-GPU plumbing configuration.  Rank 0 packs the weights and the blob
 broadcast; every rank then processes its own batch (weak scaling, no data-path collective).  The line carries `n_gpus` =
 the world size of the process group, the per-rank images/sec, and the broadcast's bytes and time.
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  * `roofline`      MFMA implicit-GEMM kernel family (hipEvent timed on the launch stream in a dedicated pass) and, under
-                    `roofline.groupnorm`, the HBM-bound GroupNorm family measured the same way;
-  * `cpu_baseline`  the CPU oracle timed on this host (N = 1 only, bounded sample);
-  * `parity_vs_cpu_oracle` / `value_at_parity`  image PSNR, latent PSNR and VQ code agreement of the headline policy and of
-                    the parity-qualified policy (split-precision encoder + UNet, fp16 decoder) against the CPU oracle on the
-                    first images of the batch, and the throughput of that policy;
-  * `torch_rocm_autocast_baseline`  the same restatement of the reference run with stock PyTorch-ROCm ops on this GPU under
-                    torch.autocast(fp16) (what sampler.py:185 does): its images/sec and ITS parity against the fp32 CPU path.
+Rank 0 prints ONE JSON line with the contract fields.  EVERYTHING at the top level of the line - `value`, `ms_per_step`, `dtype`,
+`roofline` (+ `per_kernel`, `groupnorm`, `traffic`), `cpu_baseline.gpu_vs_cpu_psnr_db` - describes ONE precision policy, the one
+`--precision` names.  The default is `parity` (split-precision encoder + UNet, fp16 decoder): the fastest policy that meets
+north_star's tolerance (image PSNR >= 60 dB against the reference CPU path).  Beside it:
+  * `roofline`      MFMA implicit-GEMM kernel family of the headline pass (hipEvent timed on the launch stream in a dedicated pass),
+                    `roofline.per_kernel` per kernel family, `roofline.groupnorm` the HBM-bound GroupNorm family, all live;
+                    `roofline.traffic` / `roofline.offline_rocprofv3` replay digest-stamped rocprofv3 results of this command from
+                    profiles/ (a process cannot attach rocprofv3 to itself) and say so;
+  * `cpu_baseline`  the CPU oracle timed on this host (N = 1 only, bounded sample: the first 8 images) + the unmodified reference modules'
+                    own number from profiles/ref_cpu_timing.json (build container; oracle/time_reference.py);
+  * `parity_vs_cpu_oracle`  image PSNR, latent PSNR and VQ code agreement of the headline policy against the CPU oracle on up to
+                    `--parity-images` (default: all 32) images of the batch, per-image minimum included;
+  * `value_fp16_unqualified`  the all-fp16 policy (BASELINE.json's dtype) timed the same way, with ITS parity: fast, and below the tolerance;
+  * `torch_rocm_autocast_restatement_baseline`  the oracle's restatement of the reference run with stock PyTorch-ROCm ops on this GPU under
+                    torch.autocast(fp16) (what sampler.py:185 does) at the bench batch: its images/sec and ITS parity against the fp32 CPU path.
 """
 from __future__ import annotations
 
@@ -124,6 +130,22 @@ def psnr_db(a, b, p2p):
     return float("inf") if mse == 0 else float(10 * np.log10(p2p * p2p / mse))
 
 
+def offline_profile(kind: str, precision: str, config: str, B: int):
+    """digest-stamped rocprofv3 results of THIS command collected offline (scripts/collect_traffic.py / collect_gn_trace.py) - or
+    (None, why) when the file is missing, was measured on other kernel sources, or for another workload"""
+    path = os.path.join(ROOT, "profiles", f"r4_{kind}_{precision}.json")
+    if not (config == "realsr" and B == 32):
+        return None, "offline rocprofv3 files exist for the default workload only"
+    if not os.path.exists(path):
+        return None, f"{os.path.relpath(path, ROOT)} not collected"
+    with open(path) as fh:
+        j = json.load(fh)
+    if j.get("kernel_source_digest") != kernel_source_digest():
+        return None, f"{os.path.relpath(path, ROOT)} was collected on other kernel sources: not reported"
+    j["file"] = os.path.relpath(path, ROOT)
+    return j, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,11 +153,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="realsr", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the config's BASELINE batch)")
-    ap.add_argument("--precision", default=os.environ.get("RESSHIFT_PRECISION", "fp16"))
-    ap.add_argument("--parity-images", type=int, default=8, help="images of the batch compared with the CPU oracle")
+    ap.add_argument("--precision", default=os.environ.get("RESSHIFT_PRECISION", PARITY_POLICY),
+                    help="the policy the whole line describes (default: parity = the fastest policy that meets the 60 dB tolerance)")
+    ap.add_argument("--parity-images", type=int, default=32, help="images of the batch compared with the CPU oracle (chunks of 8)")
+    ap.add_argument("--cpu-seconds", type=float, default=240.0, help="budget of CPU-oracle time: further chunks of 8 images are skipped once it is spent")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline / parity legs)")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--no-exact-leg", action="store_true", help="skip the fp32-policy parity/timing leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary policies (fp16 / parity beside the headline)")
+    ap.add_argument("--mixed-leg", action="store_true", help="also time the parity_mixed mixture (reported, never credited)")
+    ap.add_argument("--exact-leg", action="store_true", help="also run the fp32-policy parity/timing leg (one pass)")
+    ap.add_argument("--no-exact-leg", action="store_true", help=argparse.SUPPRESS)   # (round-3 flag, now the default)
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
     args = ap.parse_args()
 
@@ -208,61 +235,52 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
-    headline = (pu, pe, pd)
-    for i in range(args.warmup):
-        out = run(headline)
+    def timed_all_ranks(pol, n, warm):
+        """barrier-bracketed, max over ranks: the contract's timed region"""
+        for i in range(warm):
+            o = run(pol)
+            torch.cuda.synchronize()
+            log(f"warmup pass {i} done (arena {eng.arena_bytes() / 2**30:.2f} GiB)")
         torch.cuda.synchronize()
-        log(f"warmup pass {i} done (arena {eng.arena_bytes() / 2**30:.2f} GiB)")
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run(headline)
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            o = run(pol)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t, o
+
+    headline = (pu, pe, pd)
+    elapsed, out = timed_all_ranks(headline, args.steps, args.warmup)
     per_rank = sharding.allgather_floats([elapsed, float(torch.cuda.current_device())], dev)
     elapsed = sharding.allreduce_max(elapsed, dev)
     assert torch.isfinite(out).all().item(), "non-finite output"
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    log(f"timed region done: {ms_per_step:.1f} ms/step, {value:.2f} img/s")
-
-    # ---- N > 1: the parity-qualified policy timed across all ranks exactly like the headline (barriers, max over ranks), so that the
-    # scaling curve exists for the credited policy too.  Its parity against the CPU oracle is established by the N = 1 line
-    # (`value_at_parity`) and the GPU tests; this leg only times it.
-    value_parity_policy = None
-    if world > 1 and args.precision != PARITY_POLICY:
-        polp = policy_args(PARITY_POLICY, steps)
-        for _ in range(max(1, args.warmup)):
-            run(polp)
-        torch.cuda.synchronize()
-        sharding.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run(polp)
-        torch.cuda.synchronize()
-        sharding.barrier()
-        torch.cuda.synchronize()
-        el_p = sharding.allreduce_max(time.perf_counter() - t0, dev)
-        value_parity_policy = {"value": round(world * B * args.steps / el_p, 3), "unit": "images/sec", "ms_per_step": round(el_p / args.steps * 1e3, 3),
-                               "policy": PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", "n_gpus": world, "steps": args.steps,
-                               "note": "timed like `value` (barrier-bracketed, max over ranks); the policy's parity against the CPU oracle is "
-                                       "checked in the N = 1 line (`value_at_parity`) and in tests/test_engine_gpu.py"}
-        log(f"parity policy across {world} ranks: {value_parity_policy['value']} img/s")
-
-    # ---- roofline of the dominant kernel family (MFMA implicit GEMM) and of the GroupNorm family, measured in a dedicated
-    # pass with hipEvents on the launch stream
-    roofline = None
     launches = eng.last_launch_count()
-    if rank == 0 and not args.no_profile_pass:
+    log(f"timed region done ({args.precision}): {ms_per_step:.1f} ms/step, {value:.2f} img/s, {launches} kernel launches per step")
+
+    # ---- N > 1: the OTHER reference policy (fp16 when the headline is parity, parity otherwise) timed across all ranks exactly like the
+    # headline (barriers, max over ranks), so that the scaling curve exists for both.  Parity against the CPU oracle is an N = 1 matter.
+    other_policy_all_ranks = None
+    if world > 1 and not args.no_secondary:
+        oname = "fp16" if args.precision == PARITY_POLICY else PARITY_POLICY
+        el_p, _ = timed_all_ranks(policy_args(oname, steps), args.steps, max(1, args.warmup))
+        el_p = sharding.allreduce_max(el_p, dev)
+        other_policy_all_ranks = {"policy": oname, "value": round(world * B * args.steps / el_p, 3), "unit": "images/sec",
+                                  "ms_per_step": round(el_p / args.steps * 1e3, 3), "n_gpus": world, "steps": args.steps,
+                                  "note": "timed like `value` (barrier-bracketed, max over ranks)"}
+        log(f"{oname} policy across {world} ranks: {other_policy_all_ranks['value']} img/s")
+
+    def profile_pass(pol, pname):
+        """one pass with hipEvent brackets around every MFMA-family and GroupNorm launch (on the launch stream): the `roofline` block"""
         eng.profile_enable(True)
-        run(headline)
+        run(pol)
         torch.cuda.synchronize()
         st = eng.profile_get()
+        per_kernel = per_kernel_rooflines(eng)
         eng.profile_enable(False)
         fl = {"fp16": st["flops_f16"], "fp32": st["flops_f32"], "split": st["flops_split"]}
         tot = sum(fl.values())
@@ -270,60 +288,64 @@ def main():
         # time-weighted peak when a policy mixes MFMA flavours: peak_eff = total flops / sum(flops_i / peak_i)
         peak_eff = tot / sum(v / MFMA_PEAK_TFLOPS[k] for k, v in fl.items()) if tot else MFMA_PEAK_TFLOPS["fp16"]
         achieved = tot / (st["igemm_ms"] * 1e-3) / 1e12 if st["igemm_ms"] > 0 else 0.0
-        # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
-        # passes of this very command, corrected as MI355X_MICROARCH.md prescribes) - collected offline by
-        # scripts/collect_traffic.py into profiles/, because a process cannot attach rocprofv3 to itself.  The file is
-        # stamped with the digest of the kernel sources it was measured on; a stale file is not reported.
-        traffic = traffic_note = None
-        tpath = os.path.join(ROOT, "profiles", f"r3_pmc_traffic_{args.precision}.json")
-        gn_traffic = gn_trace_ms = None
-        if args.config == "realsr" and B == 32 and os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("kernel_source_digest") == kernel_source_digest():
-                traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)  # MB per launch
-                if tj.get("groupnorm", {}).get("launches_fetch_pass"):
-                    gn_traffic = round(tj["groupnorm"]["hbm_bytes_per_launch"] / 1e6, 3)
-            else:
-                traffic_note = "profiles/ PMC file was collected on different kernel sources: not reported"
-        roofline = {
-            "bound": "mfma", "kernel": "igemm4_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_split_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / win_attn_qkv*_kernel / ae_flash_attn_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
+        roof = {
+            "bound": "mfma", "policy": pname,
+            "kernel": "igemm4_kernel<*> (dominant: halo 3x3 conv) / igemm_split_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / "
+                      "win_attn_qkv*_kernel / ae_flash_attn*_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
             "achieved": round(achieved, 2), "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
-            "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_note": traffic_note,
+            "peak_note": "time-weighted dense MFMA peak of the arithmetic this policy runs: split storage = three fp16 MFMAs per product (2500 / 3), fp16 2500, fp32 157.3 TFLOP/s",
+            "frac_of_fp16_peak_algorithmic": round(achieved / MFMA_PEAK_TFLOPS["fp16"], 4),
+            "traffic": None, "traffic_unit": "MB of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": None,
             "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),
             "algorithmic_gflop_per_launch": round(tot / max(1, st["igemm_launches"]) / 1e9, 2),
             "launches_per_step": st["igemm_launches"], "avg_launch_us": round(st["igemm_ms"] * 1e3 / max(1, st["igemm_launches"]), 2),
             "algorithmic_gflop_per_image_igemm": round(tot / B / 1e9, 1), "algorithmic_gflop_per_image_total": gflop_per_image,
             "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(gflop_per_image * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
             "dominant_precision": dom,
+            # per kernel family (north_star: "per-kernel achieved-fraction-of-roofline"): same hipEvent brackets, grouped
+            "per_kernel": per_kernel,
         }
-        # per kernel family (north_star: "per-kernel achieved-fraction-of-roofline"): same hipEvent brackets, grouped
-        roofline["per_kernel"] = per_kernel_rooflines(eng)
-        # GroupNorm family time from the committed rocprofv3 kernel trace of this command (scripts/collect_gn_trace.py; digest-stamped):
-        # the hipEvent brackets cannot resolve 6 - 14 us kernels (their fixed cost is comparable to the kernels), the trace can
-        gpath = os.path.join(ROOT, "profiles", f"r3_gn_trace_{args.precision}.json")
-        if args.config == "realsr" and B == 32 and os.path.exists(gpath):
-            with open(gpath) as fh:
-                gj = json.load(fh)
-            if gj.get("kernel_source_digest") == kernel_source_digest():
-                gn_trace_ms = gj["ms_per_pass"]
+        # HBM traffic of the same kernel family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
+        # very command, corrected as MI355X_MICROARCH.md prescribes) - collected offline by scripts/collect_traffic.py into profiles/,
+        # because a process cannot attach rocprofv3 to itself.  Stamped with the digest of the kernel sources; a stale file is not reported.
+        tj, why = offline_profile("pmc_traffic", pname, args.config, B)
+        if tj:
+            roof["traffic"] = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
+            roof["traffic_source"] = f"replayed from {tj['file']} (offline rocprofv3 --pmc of this command on these kernel sources, not observed by this run)"
+        else:
+            roof["traffic_source"] = why
         if st.get("gn_launches"):
-            gn_ms = gn_trace_ms if gn_trace_ms else st["gn_ms"]
-            gbs = st["gn_bytes"] / (gn_ms * 1e-3) / 1e9 if gn_ms > 0 else 0.0
-            roofline["groupnorm"] = {
+            gbs = st["gn_bytes"] / (st["gn_ms"] * 1e-3) / 1e9 if st["gn_ms"] > 0 else 0.0
+            gn = {
                 "bound": "hbm", "kernel": "gn_stats_kernel / gn_apply_kernel / gn_fused_kernel (GroupNorm32 + SiLU / FiLM)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_mb_per_launch": round(st["gn_bytes"] / st["gn_launches"] / 1e6, 3),
-                "note": "algorithmic bytes = every GroupNorm input read once + every output written once",
-                "launches_per_step": st["gn_launches"], "avg_launch_us": round(gn_ms * 1e3 / st["gn_launches"], 2),
-                "ms_per_step": round(gn_ms, 2), "ms_per_step_source": "rocprofv3 kernel trace (profiles/)" if gn_trace_ms else "hipEvent brackets",
-                "ms_per_step_hipevents": round(st["gn_ms"], 2), "traffic": gn_traffic,
-                "traffic_unit": "MB of HBM traffic per kernel launch of the family (PMC)",
+                "note": "live hipEvent brackets (they over-credit 6 - 14 us kernels: see offline_rocprofv3); algorithmic bytes = every GroupNorm pass's "
+                        "input read once + output written once, nothing where producer and consumer fold the normalisation",
+                "launches_per_step": st["gn_launches"], "avg_launch_us": round(st["gn_ms"] * 1e3 / st["gn_launches"], 2), "ms_per_step": round(st["gn_ms"], 2),
+                "traffic": round(tj["groupnorm"]["hbm_bytes_per_launch"] / 1e6, 3) if tj and tj.get("groupnorm", {}).get("launches_fetch_pass") else None,
+                "traffic_unit": "MB of HBM traffic per kernel launch of the family (PMC; replayed like roofline.traffic)",
             }
+            gj, gwhy = offline_profile("gn_trace", pname, args.config, B)
+            if gj:   # the rocprofv3 kernel trace resolves the small kernels; reported BESIDE the live figure, labelled
+                gn["offline_rocprofv3"] = {"source": f"replayed from {gj['file']} (rocprofv3 --kernel-trace of this command on these kernel sources)",
+                                           "ms_per_step": round(gj["ms_per_pass"], 2), "kernel_launches_per_step": gj["launches_per_pass"],
+                                           "achieved_gbs": round(st["gn_bytes"] / (gj["ms_per_pass"] * 1e-3) / 1e9, 1),
+                                           "frac": round(st["gn_bytes"] / (gj["ms_per_pass"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            else:
+                gn["offline_rocprofv3"] = gwhy
+            roof["groupnorm"] = gn
+        return roof
 
-    # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload; parity
-    # of the GPU policies against it on the same images
-    cpu_baseline = parity = value_at_parity = torch_baseline = None
+    roofline = None
+    if rank == 0 and not args.no_profile_pass:
+        roofline = profile_pass(headline, args.precision)
+        log(f"roofline ({args.precision}): {roofline['achieved']} of {roofline['peak']} TFLOP/s")
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload; parity of the GPU
+    # policies against it on (up to) all images of the batch
+    cpu_baseline = parity = value_at_parity = value_fp16 = torch_baseline = None
+    extra = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import resshift_oracle as oc  # checker / baseline only; never on the measured GPU path
 
@@ -333,91 +355,136 @@ def main():
         except AttributeError:
             usable = os.cpu_count() or 1
         torch.set_num_threads(max(1, min(usable, torch.get_num_threads(), 64)))
-        nb = max(1, min(args.parity_images, B))
-        log(f"cpu baseline: oracle on {torch.get_num_threads()} threads, {nb} images")
         usd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         asd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
-        yc = y[:nb].cpu()
-        nz = [noise[k, :nb].cpu() for k in range(steps + 1)]
-        mc = mask[:nb].cpu() if mask is not None else None
-        t0 = time.perf_counter()
-        ref, ref_aux = oc.sample_loop(usd, up, asd, aep, dp, yc, nz, mask=mc, return_aux=True)
-        cpu_s = time.perf_counter() - t0
-        zr = ref_aux["z_final"]
+        CH = 8                                        # images per oracle call: the TIMED sample is the first chunk
+        want = max(1, min(args.parity_images, B))
+        refs, zrefs, irefs, cpu_first_s, cpu_total_s, nb = [], [], [], None, 0.0, 0
+        log(f"cpu baseline: oracle on {torch.get_num_threads()} threads, chunks of {CH} images, up to {want} images / {args.cpu_seconds:.0f} s")
+        while nb < want:
+            n1 = min(CH, want - nb)
+            if nb and cpu_total_s + cpu_total_s / nb * n1 > args.cpu_seconds:
+                log(f"cpu budget spent after {nb} images ({cpu_total_s:.0f} s)")
+                break
+            sl = slice(nb, nb + n1)
+            t0 = time.perf_counter()
+            r_img, r_aux = oc.sample_loop(usd, up, asd, aep, dp, y[sl].cpu(), [noise[k, sl].cpu() for k in range(steps + 1)],
+                                          mask=mask[sl].cpu() if mask is not None else None, return_aux=True)
+            dt = time.perf_counter() - t0
+            if cpu_first_s is None:
+                cpu_first_s, first_n = dt, n1
+            cpu_total_s += dt
+            refs.append(r_img); zrefs.append(r_aux["z_final"]); irefs.append(r_aux["indices"].reshape(n1, -1))
+            nb += n1
+            log(f"  oracle images {sl.start}..{sl.stop - 1}: {dt:.1f} s")
+        ref, zr, iref = torch.cat(refs), torch.cat(zrefs), torch.cat(irefs)
         hw = zr.shape[2] * zr.shape[3]
+        zp2p = (zr.max() - zr.min()).item()
 
         def parity_of(name, img, z, idx):
-            """image / latent PSNR and VQ code agreement against the CPU oracle (first nb images of the batch)"""
+            """image / latent PSNR and VQ code agreement against the CPU oracle (first nb images of the batch), whole sample and worst image"""
+            img = img[:nb].float().cpu().clamp(-1, 1)
+            z = z[:nb].float().cpu()
+            same = (idx.reshape(-1)[: nb * hw].cpu().long().reshape(nb, hw) == iref)
+            per_img = [psnr_db(img[i], ref[i].clamp(-1, 1), 2.0) for i in range(nb)]
             return {"policy": name, "images": nb,
-                    "image_psnr_db": round(psnr_db(img[:nb].float().cpu().clamp(-1, 1), ref.clamp(-1, 1), 2.0), 1),
-                    "latent_psnr_db": round(psnr_db(z[:nb].float().cpu(), zr, (zr.max() - zr.min()).item()), 1),
-                    "vq_code_agreement": round((idx.reshape(-1)[: nb * hw].cpu().long() == ref_aux["indices"].reshape(-1)).float().mean().item(), 5)}
+                    "image_psnr_db": round(psnr_db(img, ref.clamp(-1, 1), 2.0), 1), "image_psnr_db_worst_image": round(min(per_img), 1),
+                    "latent_psnr_db": round(psnr_db(z, zr, zp2p), 1),
+                    "vq_code_agreement": round(same.float().mean().item(), 5),
+                    "vq_code_agreement_worst_image": round(same.float().mean(dim=1).min().item(), 5),
+                    "vq_codes_flipped": int((~same).sum().item())}
 
         def engine_parity(name, pol):
             o, aux = run(pol, return_aux=True)
             torch.cuda.synchronize()
             return parity_of(name, o, aux["z_final"], aux["indices"])
 
-        parity = [engine_parity(args.precision, headline)]
-        cpu_baseline = {"value": round(nb / cpu_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                        "what": "oracle/ (functional restatement of the reference on torch CPU ops; 20-35 % FASTER than the reference "
-                                "modules' own loop at B=1 (box-dependent, oracle/make_golden.py), so GPU/CPU ratios are understated)",
-                        "sample": f"{nb} images, same weights/inputs/noise as the first {nb} images of the GPU batch, full {steps}-step loop, fp32",
-                        "seconds": round(cpu_s, 2), "gpu_vs_cpu_psnr_db": parity[0]["image_psnr_db"]}
-        log(f"cpu baseline {cpu_baseline['value']} img/s; headline parity {parity[0]}")
-        # the parity-qualified policy: throughput + parity on the same inputs
-        if args.precision != PARITY_POLICY:
-            pol = policy_args(PARITY_POLICY, steps)
-            par = engine_parity(PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)", pol)
+        def meets(p):
+            return bool(p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999)
+
+        hp = engine_parity(args.precision, headline)
+        hp["meets_criterion"] = meets(hp)
+        parity = [hp]
+        ref_mod = None
+        rpath = os.path.join(ROOT, "profiles", "ref_cpu_timing.json")
+        if os.path.exists(rpath):
+            with open(rpath) as fh:
+                rj = json.load(fh)
+            ref_mod = {"what": "the UNMODIFIED reference modules' own p_sample_loop, measured by oracle/time_reference.py in the build container "
+                               "(the reference tree does not exist on the GPU box) - read from profiles/ref_cpu_timing.json, not timed by this run",
+                       "cores": rj.get("cores"), "cpu": rj.get("cpu"), "torch": rj.get("torch"),
+                       "images_per_sec_by_batch": {str(r["batch"]): r["reference_images_per_sec"] for r in rj.get("rows", [])},
+                       "oracle_over_reference_speed_same_host": {str(r["batch"]): r["oracle_over_reference"] for r in rj.get("rows", [])}}
+        cpu_baseline = {"value": round(first_n / cpu_first_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                        "what": "oracle/ (functional restatement of the reference on torch CPU ops, fp32; faster than the reference modules' own loop on the "
+                                "same host by the factor in reference_modules.oracle_over_reference_speed_same_host, so GPU/CPU ratios are understated)",
+                        "sample": f"{first_n} images (the first chunk; the oracle then ran {nb - first_n} more, untimed for the baseline, for the parity check), same "
+                                  f"weights/inputs/noise as the first images of the GPU batch, full {steps}-step loop incl. VQ encode/decode",
+                        "seconds": round(cpu_first_s, 2), "oracle_seconds_total": round(cpu_total_s, 1), "reference_modules": ref_mod,
+                        "gpu_vs_cpu_psnr_db": hp["image_psnr_db"], "gpu_vs_cpu_psnr_db_worst_image": hp["image_psnr_db_worst_image"],
+                        "gpu_vs_cpu_vq_code_agreement": hp["vq_code_agreement"], "gpu_vs_cpu_images": nb, "gpu_policy": args.precision,
+                        "gpu_over_cpu": round(value / (first_n / cpu_first_s), 1)}
+        log(f"cpu baseline {cpu_baseline['value']} img/s; headline parity {hp}")
+
+        def secondary(pname, label, with_roofline=True):
+            pol = policy_args(pname, steps)
+            par = engine_parity(label, pol)
+            par["meets_criterion"] = meets(par)
             for _ in range(max(0, args.warmup - 1)):   # timed like the headline: same warm-up and step counts
                 run(pol)
             ms = timed(pol, args.steps)
             par.update({"ms_per_step": round(ms, 2), "images_per_sec": round(B / ms * 1e3, 2), "steps_timed": args.steps, "warmup": args.warmup})
-            if not args.no_profile_pass:
-                eng.profile_enable(True)
-                run(pol)
-                torch.cuda.synchronize()
-                st2 = eng.profile_get()
-                par["roofline_per_kernel"] = per_kernel_rooflines(eng)
-                if st2.get("gn_launches") and st2["gn_ms"] > 0:
-                    par["groupnorm_ms_per_step"] = round(st2["gn_ms"], 2)
-                eng.profile_enable(False)
+            if with_roofline and not args.no_profile_pass:
+                rf = profile_pass(pol, pname)
+                par["roofline"] = {k: rf[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "igemm_ms_per_step", "per_kernel")}
+                if "groupnorm" in rf:
+                    par["groupnorm_ms_per_step"] = rf["groupnorm"]["ms_per_step"]
             parity.append(par)
-            log(f"parity policy: {par}")
-            # the cheaper mixture (first MIXED_FP16_STEPS steps fp16): its own entry, timed the same way
-            if steps > MIXED_FP16_STEPS + 1:
-                polm = policy_args("parity_mixed", steps)
-                parm = engine_parity(f"parity_mixed (first {MIXED_FP16_STEPS} steps fp16, then split; split encoder, fp16 decoder)", polm)
-                msm = timed(polm, args.steps)
-                parm.update({"ms_per_step": round(msm, 2), "images_per_sec": round(B / msm * 1e3, 2), "steps_timed": args.steps})
-                parity.append(parm)
-                log(f"mixed policy: {parm}")
-        qualified = [p for p in parity if p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999 and not p["policy"].startswith("parity_mixed")]
+            log(f"{pname}: {({k: v for k, v in par.items() if k != 'roofline'})}")
+            return par
+
+        if not args.no_secondary:
+            if args.precision != "fp16":
+                pf = secondary("fp16", "fp16 (all-fp16 storage: BASELINE.json's dtype)")
+                value_fp16 = {"value": pf["images_per_sec"], "unit": "images/sec", "ms_per_step": pf["ms_per_step"], "policy": "fp16", "dtype": "f16",
+                              "image_psnr_db": pf["image_psnr_db"], "vq_code_agreement": pf["vq_code_agreement"], "images": nb,
+                              "meets_criterion": pf["meets_criterion"],
+                              "note": "NOT the headline: the reference's decoder re-quantises the latent with an 8192-way argmin (ldm/modules/vqvae/quantize.py:276-285) and "
+                                      "fp16 rounding in front of it flips VQ codes; reported because BASELINE.json's config names fp16"}
+            if args.precision != PARITY_POLICY:
+                secondary(PARITY_POLICY, PARITY_POLICY + " (split-precision encoder + UNet, fp16 decoder)")
+            if args.mixed_leg and steps > MIXED_FP16_STEPS + 1:
+                pm = secondary("parity_mixed", f"parity_mixed (first {MIXED_FP16_STEPS} steps fp16, then split; split encoder, fp16 decoder)", with_roofline=False)
+                extra["value_at_parity_mixed"] = {"value": pm["images_per_sec"], "unit": "images/sec", "policy": pm["policy"], "image_psnr_db": pm["image_psnr_db"],
+                                                  "vq_code_agreement": pm["vq_code_agreement"], "images": nb, "meets_criterion": pm["meets_criterion"]}
+        qualified = [p for p in parity if p.get("meets_criterion") and not p["policy"].startswith("parity_mixed")]
         if qualified:
             best = max(qualified, key=lambda p: p.get("images_per_sec", value))
             value_at_parity = {"value": best.get("images_per_sec", round(value, 3)), "unit": "images/sec", "policy": best["policy"],
+                               "is_headline": best is hp,
                                "criterion": "image PSNR >= 60 dB and VQ code agreement >= 0.999 vs the CPU oracle",
-                               "image_psnr_db": best["image_psnr_db"], "vq_code_agreement": best["vq_code_agreement"], "images": nb}
+                               "image_psnr_db": best["image_psnr_db"], "image_psnr_db_worst_image": best["image_psnr_db_worst_image"],
+                               "vq_code_agreement": best["vq_code_agreement"], "images": nb}
         # the exact-kernel policy beside it (fp32 storage, v_mfma_f32_16x16x4_f32)
-        if args.precision != "fp32" and not args.no_exact_leg:
+        if args.exact_leg and args.precision != "fp32":
             p32 = policy_args("fp32", steps)
             par32 = engine_parity("fp32 (exact fp32 MFMA everywhere)", p32)
             ms32 = timed(p32, 1)
             par32.update({"ms_per_step": round(ms32, 2), "images_per_sec": round(B / ms32 * 1e3, 2), "steps_timed": 1})
             parity.append(par32)
-        # SURVEY.md §8 f4: the same restatement of the reference executed by stock PyTorch-ROCm ops (MIOpen / hipBLASLt) on this
-        # GPU under torch.autocast, as sampler.py:185 runs the reference - its throughput and ITS distance from the fp32 CPU path
+        # SURVEY.md §8 f4: the restatement of the reference executed by stock PyTorch-ROCm ops (MIOpen / hipBLASLt) on this GPU under
+        # torch.autocast, as sampler.py:185 runs the reference, at the bench batch - its throughput (second call: MIOpen's find step is in
+        # the first) and ITS distance from the fp32 CPU path.  The unmodified modules themselves cannot run here (no reference tree on the
+        # GPU box); the oracle is pinned to them bit for bit on the CPU (tests/test_oracle.py).
         if not args.no_torch_baseline:
             try:
                 usd_g = {k: v.to(dev) for k, v in usd.items()}
                 asd_g = {k: v.to(dev) for k, v in asd.items()}
-                nt = min(B, 8)
-                yg, ng = y[:nt], [noise[k, :nt] for k in range(steps + 1)]
-                mg = mask[:nt] if mask is not None else None
+                ng = [noise[k] for k in range(steps + 1)]
 
                 def torch_run():
                     with torch.autocast("cuda", dtype=torch.float16):
-                        return oc.sample_loop(usd_g, up, asd_g, aep, dp, yg, ng, mask=mg, return_aux=True)
+                        return oc.sample_loop(usd_g, up, asd_g, aep, dp, y, ng, mask=mask, return_aux=True)
 
                 t0 = time.perf_counter()
                 torch_run()
@@ -427,23 +494,28 @@ def main():
                 o_t, aux_t = torch_run()
                 torch.cuda.synchronize()
                 t_s = time.perf_counter() - t0
-                tb = parity_of("torch autocast(fp16)", o_t, aux_t["z_final"], aux_t["indices"]) if nt >= nb else {}
-                torch_baseline = {"value": round(nt / t_s, 2), "unit": "images/sec", "batch": nt, "seconds": round(t_s, 3),
+                tb = parity_of("torch autocast(fp16)", o_t, aux_t["z_final"], aux_t["indices"])
+                torch_baseline = {"value": round(B / t_s, 2), "unit": "images/sec", "batch": B, "seconds": round(t_s, 3),
                                   "first_call_seconds": round(first_s, 2),
-                                  "what": "oracle/ restatement on PyTorch-ROCm CUDA ops under torch.autocast(float16), eager",
-                                  "parity_vs_cpu_fp32": tb}
+                                  "what": "oracle/ RESTATEMENT of the reference (not the unmodified modules) on PyTorch-ROCm CUDA ops under torch.autocast(float16), "
+                                          "eager, batch = the bench batch, second call (MIOpen find-db warm)",
+                                  "parity_vs_cpu_fp32": tb, "engine_over_torch": round(value / (B / t_s), 1)}
                 log(f"torch autocast baseline: {torch_baseline}")
+                del usd_g, asd_g, o_t, aux_t
+                torch.cuda.empty_cache()
             except Exception as ex:  # the baseline is informational: never fail the bench line over it
                 torch_baseline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank == 0:
         dtypes = sorted(set(pu) | {pe, pd})
+        names = {"fp16": "f16", "fp32": "f32", "split": "f16x2 (hi+lo fp16 pairs, 3 MFMAs per product: fp32-class)"}
         line = {
             "metric": f"images/sec ({cdesc.split(',')[0]}, {steps}-step ResShift sampling loop incl. VQ encode/decode)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_diffusion_step": round(ms_per_step / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp16": "f16", "fp32": "f32", "split": "f16x2 (hi+lo pairs, 3 MFMAs per product)"}.get(dtypes[0], dtypes[0]) if len(dtypes) == 1
+            "dtype": names.get(dtypes[0], dtypes[0]) if len(dtypes) == 1 else
+                     f"f16x2 encoder + UNet (hi+lo fp16 pairs, 3 MFMAs per product: fp32-class) + f16 decoder ({args.precision} policy)" if args.precision == PARITY_POLICY
                      else "+".join(dtypes) + f" ({args.precision})",
             "data": "synthetic",
             "config": {"workload": f"{cname}: batch {B}/GPU x {world} GPU, {cdesc}, random-init weights",
@@ -455,14 +527,11 @@ def main():
                       "per_rank": [{"rank": r, "device": int(v[1]), "images_per_sec": round(B * args.steps / v[0], 3)} for r, v in enumerate(per_rank)],
                       "weight_broadcast_bytes": int(getattr(eng, "broadcast_bytes", 0)),
                       "weight_broadcast_ms": round(1e3 * float(getattr(eng, "broadcast_s", 0.0)), 3)},
-            "value_at_parity": value_at_parity, "value_parity_policy": value_parity_policy,
-            "value_at_parity_mixed": next(({"value": p["images_per_sec"], "unit": "images/sec", "policy": p["policy"], "image_psnr_db": p["image_psnr_db"],
-                                            "vq_code_agreement": p["vq_code_agreement"], "images": p["images"],
-                                            "meets_criterion": bool(p["image_psnr_db"] >= 60.0 and p["vq_code_agreement"] >= 0.999)}
-                                           for p in (parity or []) if p["policy"].startswith("parity_mixed")), None),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
-            "torch_rocm_autocast_baseline": torch_baseline,
+            "value_at_parity": value_at_parity, "value_fp16_unqualified": value_fp16, "other_policy_all_ranks": other_policy_all_ranks,
+            "torch_rocm_autocast_restatement_baseline": torch_baseline,
         }
+        line.update(extra)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -1,0 +1,182 @@
+"""CPU study: can the three-MFMA split product become "two-MFMA-equivalent" by running its cross
+terms on the MX-fp8 matrix path?  Decided here, with zero GPU minutes.
+
+The engine's split-precision product (resshift_amd/csrc/igemm4_kernel.h, igemm_split.hip) is
+    W.X = Wh.Xh + 2^-11 (Wh.Xl + Wl.Xh),      x = hi + lo 2^-11,  hi = fp16(x),  lo = fp16((x - hi) 2^11)
+as three fp16 MFMAs.  The proposal: keep Wh.Xh in fp16 and form BOTH cross terms with `v_mfma_scale_f32_16x16x128_f8f6f4` (twice
+the fp16 rate), i.e. with all four cross operands quantised to e4m3 with one power-of-two scale per 32 consecutive K elements (MX
+block format).  The criterion is north_star's (image PSNR >= 60 dB) together with VQ code agreement >= 99.9 % against the fp32
+CPU path - the quantity the decoder's 8192-way argmin (ldm/modules/vqvae/quantize.py:276-285) turns rounding error into.
+
+This script patches the ORACLE's conv / linear helper (every Conv2d and Linear of the encoder and the UNet goes through
+`resshift_oracle._conv` / `_linear`) with an emulation of the arithmetic under test and runs the whole sampling loop:
+    exact      : fp32 (the reference CPU path: the thing compared against)
+    fp16       : operands rounded to fp16, fp32 accumulation            (the engine's fp16 policy; calibrates the emulation)
+    split3     : the three-term product above, fp16 hi / lo operands     (the engine's parity policy)
+    fp8cross   : Wh.Xh in fp16 + cross terms on MX-e4m3 operands         (the proposal)
+    bf8cross   : the same with e5m2 (more range, 2 mantissa bits)
+The attention matmuls, GroupNorm, softmax and the decoder stay fp32 in every mode, which FAVOURS the proposal (the engine runs
+the attention products in split arithmetic as well and the decoder in fp16); a mode that fails here fails on the GPU.
+
+    python -m oracle.study_fp8_cross [--config realsr] [--images 2] [--modes fp16 split3 fp8cross]
+
+Writes profiles/r4_fp8_cross_study.json.  Test infrastructure only: nothing on the product path imports it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import resshift_oracle as oc  # noqa: E402
+from resshift_amd.config import load_config, to_plain  # noqa: E402
+from resshift_amd.spec import ae_param_spec, random_state_dict, unet_param_spec  # noqa: E402
+
+CONFIGS = {"realsr": ("realsr_swinunet_realesrgan256", 64), "journal": ("realsr_swinunet_realesrgan256_journal", 64),
+           "faceir": ("faceir_gfpgan512_lpips", 512), "inpaint": ("inpaint_lama256_imagenet", 256)}
+LO = 2048.0
+
+
+def split16(x):
+    hi = x.half().float()
+    lo = ((x - hi) * LO).half().float()
+    return hi, lo
+
+
+def mx_quant(x, dim, fmt):
+    """MX block quantisation along `dim`: blocks of 32 consecutive elements share one power-of-two scale (E8M0); elements are
+    e4m3 (max 448) or e5m2 (max 57344).  Returned as fp32 values (scale x element): what the scaled MFMA multiplies."""
+    dt = torch.float8_e4m3fn if fmt == "e4m3" else torch.float8_e5m2
+    xm = x.movedim(dim, -1)
+    n = xm.shape[-1]
+    pad = (-n) % 32
+    if pad:
+        xm = F.pad(xm, (0, pad))
+    blk = xm.reshape(*xm.shape[:-1], -1, 32)
+    amax = blk.abs().amax(dim=-1, keepdim=True).clamp_min(1e-38)
+    # shared power-of-two scale chosen so that the block maximum does not saturate (the OCP rule floor(log2 amax) - emax clips the top
+    # quarter-octave; the non-saturating choice is the more accurate one and the one a kernel author would pick)
+    fmax = 448.0 if fmt == "e4m3" else 57344.0
+    scale = torch.exp2(torch.ceil(torch.log2(amax / fmax)))
+    q = (blk / scale).clamp(-fmax, fmax).to(dt).float() * scale
+    q = q.reshape(*xm.shape[:-1], -1)[..., :n]
+    return q.movedim(-1, dim).contiguous()
+
+
+MODE = "exact"
+
+
+def emu_conv(sd, name, x, stride=1, padding=0):
+    w, b = sd[name + ".weight"], sd[name + ".bias"]
+    if MODE == "exact":
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+    if MODE == "fp16":
+        return F.conv2d(x.half().float(), w.half().float(), b, stride=stride, padding=padding)
+    wh, wl = split16(w)
+    xh, xl = split16(x)
+    main = F.conv2d(xh, wh, None, stride=stride, padding=padding)
+    if MODE == "split3":
+        cross = F.conv2d(xl, wh, None, stride=stride, padding=padding) + F.conv2d(xh, wl, None, stride=stride, padding=padding)
+    else:
+        fmt = "e4m3" if MODE == "fp8cross" else "e5m2"
+        # K runs over (tap, input channel) with the channels contiguous: blocks of 32 along the channel dimension
+        q = lambda t: mx_quant(t, 1, fmt)  # noqa: E731
+        cross = F.conv2d(q(xl), q(wh), None, stride=stride, padding=padding) + F.conv2d(q(xh), q(wl), None, stride=stride, padding=padding)
+    return main + cross / LO + b.view(1, -1, 1, 1)
+
+
+def emu_linear(sd, name, x):
+    w, b = sd[name + ".weight"], sd[name + ".bias"]
+    if MODE == "exact" or x.dim() < 2 or x.shape[-1] < 32 or ".emb_layers." in name or name.startswith("time_embed"):
+        return F.linear(x, w, b)           # (the timestep-embedding MLPs run in fp32 on the engine in every policy)
+    if MODE == "fp16":
+        return F.linear(x.half().float(), w.half().float(), b)
+    wh, wl = split16(w)
+    xh, xl = split16(x)
+    main = F.linear(xh, wh)
+    if MODE == "split3":
+        cross = F.linear(xl, wh) + F.linear(xh, wl)
+    else:
+        fmt = "e4m3" if MODE == "fp8cross" else "e5m2"
+        cross = F.linear(mx_quant(xl, -1, fmt), mx_quant(wh, -1, fmt)) + F.linear(mx_quant(xh, -1, fmt), mx_quant(wl, -1, fmt))
+    return main + cross / LO + b
+
+
+def psnr(a, b, p2p):
+    mse = torch.mean((a.double() - b.double()) ** 2).item()
+    return float("inf") if mse == 0 else float(10 * torch.log10(torch.tensor(p2p * p2p / mse)))
+
+
+def main():
+    global MODE
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", nargs="+", default=["realsr"])
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--modes", nargs="+", default=["fp16", "split3", "fp8cross"])
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_fp8_cross_study.json"))
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    oc._conv, oc._linear = emu_conv, emu_linear
+    orig_decode = oc.vq_decode
+
+    def decode_exact(*a, **k):          # the decoder (behind the argmin) is not part of the question
+        global MODE
+        m, MODE = MODE, "exact"
+        try:
+            return orig_decode(*a, **k)
+        finally:
+            MODE = m
+
+    oc.vq_decode = decode_exact
+    results = {"what": __doc__.split("\n\n")[0], "criterion": "image PSNR >= 60 dB AND VQ code agreement >= 0.999 on every image", "runs": []}
+    if os.path.exists(args.out):
+        with open(args.out) as fh:
+            results = json.load(fh)
+    for cname in args.config:
+        yaml, lr = CONFIGS[cname]
+        cfg = to_plain(load_config(yaml))
+        up, aep, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+        steps = int(dp["steps"])
+        uspec, _ = unet_param_spec(up)
+        usd, asd = random_state_dict(uspec, seed=1), random_state_dict(ae_param_spec(aep), seed=2)   # bench.py's weights
+        g = torch.Generator().manual_seed(1000)                                                          # bench.py's rank-0 inputs
+        f = 2 ** (len(aep["ddconfig"]["ch_mult"]) - 1)
+        sf = int(dp.get("sf", 4))
+        hz, cz, B = lr * sf // f, int(aep["embed_dim"]), args.images
+        y = torch.rand(32 if cname != "faceir" else 16, 3, lr, lr, generator=g)[:B] * 2 - 1
+        noise = torch.randn(steps + 1, B, cz, hz, hz, generator=g)
+        mask = (torch.rand(B, 1, lr, lr, generator=g) > 0.7).float() * 2 - 1 if up.get("cond_mask", False) else None
+        nz = [noise[k] for k in range(steps + 1)]
+        MODE = "exact"
+        t0 = time.time()
+        ref, raux = oc.sample_loop(usd, up, asd, aep, dp, y, nz, mask=mask, return_aux=True)
+        print(f"[{cname}] exact: {time.time() - t0:.0f} s", flush=True)
+        zr, ir = raux["z_final"], raux["indices"].reshape(B, -1)
+        for mode in args.modes:
+            MODE = mode
+            t0 = time.time()
+            img, aux = oc.sample_loop(usd, up, asd, aep, dp, y, nz, mask=mask, return_aux=True)
+            same = aux["indices"].reshape(B, -1) == ir
+            per = [psnr(img[i].clamp(-1, 1), ref[i].clamp(-1, 1), 2.0) for i in range(B)]
+            row = {"config": cname, "mode": mode, "images": B, "latent_psnr_db": round(psnr(aux["z_final"], zr, (zr.max() - zr.min()).item()), 1),
+                   "vq_code_agreement": round(same.float().mean().item(), 5), "vq_code_agreement_worst_image": round(same.float().mean(1).min().item(), 5),
+                   "image_psnr_db": round(psnr(img.clamp(-1, 1), ref.clamp(-1, 1), 2.0), 1), "image_psnr_db_worst_image": round(min(per), 1),
+                   "seconds": round(time.time() - t0)}
+            row["meets_criterion"] = bool(row["image_psnr_db_worst_image"] >= 60.0 and row["vq_code_agreement_worst_image"] >= 0.999)
+            print(row, flush=True)
+            results["runs"] = [r for r in results["runs"] if not (r["config"] == cname and r["mode"] == mode and r["images"] == B)] + [row]
+            with open(args.out, "w") as fh:
+                json.dump(results, fh, indent=1)
+    MODE = "exact"
+
+
+if __name__ == "__main__":
+    main()

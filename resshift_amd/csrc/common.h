@@ -176,6 +176,25 @@ template <> struct Vec8<h2s> {
 
 // ---- launch parameter blocks (plain C structs, passed by value) ------------
 
+// One GroupNorm whose coefficients are produced by a tail.  `coef == nullptr`: no tail on this launch.
+struct GNTail {
+    const float* gamma; const float* beta;
+    const float* film;        // optional [2 * C] FiLM row (scale then shift) of this timestep, or null
+    float* coef;              // out: [B][2][C] (scale row, shift row) - GNParams::coef / IGemmParams::xcoef / WinAttnParams::xcoef
+    unsigned* ticket;         // [B] arrival counters of THIS tail, zero when the launch starts
+    int expected;             // contributing workgroups per image
+    int C, groups, HW;        // channels of the normalised tensor (both segments together), groups (32), pixels per image
+    float eps;
+    // per-channel partial sums [B][S][ld][2] (sum, sum of squares): segment 0 covers channels [0, n0) of the normalised tensor (columns
+    // 0 .. n0 - 1 of st0's rows), segment 1 - the other half of a channel concatenation (models/unet.py:891), complete before this launch
+    // starts - channels [n0, C) (columns 0 .. C - n0 - 1 of st1's rows).  n0 == C: one segment.
+    const float* st0; int S0, ld0, n0;
+    const float* st1; int S1, ld1;
+    // alternatively per-GROUP partial sums [B][Sg][groups][2] of a statistics pass over the whole tensor (gn_stats_kernel): stg != null
+    const float* stg; int Sg;
+};
+
+
 // Implicit-GEMM convolution / GEMM (igemm.hip).  y[m][n] = sum_k X[m][k] W[n][k]
 // with X gathered on the fly from NHWC sources (im2col never materialised).
 struct IGemmParams {
@@ -207,6 +226,10 @@ struct IGemmParams {
     // that GroupNorm then needs no statistics pass over the tensor.  Deterministic (fixed summation order, no atomics).
     float* ystats;
     int ystats_ld;
+    // GroupNorm tail (gn_tail.h; halo kernel, split-K reduce-with-statistics kernel, igemm_split): tail.coef != null - the launch that
+    // completes the statistics of y also writes the consuming GroupNorm's coefficients; the engine fills the GroupNorm's parameters, the
+    // coefficient / ticket pointers and the other segment of a concatenation, the launcher the arrival count and segment 0 (= ystats)
+    GNTail tail;
 };
 
 struct DirectConvParams {
@@ -230,6 +253,8 @@ struct GNParams {
                          // so that a consumer kernel can apply y = x * scale + shift while it loads x (fused Swin kernels)
     const float* cpartial;   // non-null: per-channel partial sums [B][S][cp_ld][2] written by the producing conv's epilogue
     int cp_ld;               // (IGemmParams::ystats) replace `partial`; no statistics kernel runs
+    unsigned* ticket;        // non-null (with `coef`, without `cpartial`): [B] zeroed arrival counters - the statistics kernel's last
+                             // workgroup per image writes the coefficients itself (gn_tail.h), no second launch
 };
 
 struct WinAttnParams {

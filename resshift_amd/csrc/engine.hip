@@ -110,6 +110,7 @@ struct View {
     // optional per-channel partial statistics of this tensor, [B][stS][stld][2] floats (IGemmParams::ystats): set by whoever
     // allocates the tensor when its producer is the halo conv kernel; the consuming GroupNorm then skips its statistics pass
     float* st = nullptr; int stS = 0, stld = 0;
+    int st_prod = -1;   // sequence number of the launch that produces `st` (Exec::prod_seq): key of the GroupNorm tail plan
     long long pixels() const { return (long long)B * H * W; }
     View slice(int c0, int c) const {
         View v = *this; v.p = (char*)p + (size_t)c0 * rs_dtype_chan_bytes(dt); v.C = c;
@@ -164,8 +165,34 @@ struct Arena {
     }
 };
 
+// GroupNorm tail plan (gn_tail.h): the launch that completes a tensor's statistics also writes the coefficients of the GroupNorm that
+// consumes it.  The producer runs BEFORE the consumer is known, so the plan is made by the dry sizing pass - which walks the same
+// control flow as the real pass - and keyed by the producer's sequence number: the consuming gn_coef() call of the dry pass claims its
+// producer, the real pass attaches the tail at the producer's launch and skips the coefficient launch at the consumer.
+struct TailPlan {
+    bool on = false; int consumer = -1;
+    const float* gamma = nullptr; const float* beta = nullptr; const float* film = nullptr; float eps = 0.f;
+    int C = 0, HW = 0; size_t coef_off = 0;
+};
+
 struct Exec {
     hipStream_t st = nullptr; Arena* arena = nullptr; bool dry = false; long long launches = 0; int err = 0;
+    bool dbg = false;                        // debug trace requested (both passes): no statistics fusion, no tails
+    std::vector<TailPlan>* plan = nullptr;   // by producer sequence number
+    int prod_seq = 0, gn_seq = 0;
+    // coefficient pool ([B][2][C] affines; behind the scratch arena, reset per network body - stream order keeps reuse safe) and the
+    // ticket pool of the tails (zeroed once per call)
+    char* pool_base = nullptr; size_t pool_off = 0, pool_peak = 0;
+    unsigned* ticket_base = nullptr; size_t ticket_used = 0;
+    float* pool(size_t bytes) {
+        pool_off = (pool_off + 255) & ~(size_t)255;
+        float* q = (float*)(pool_base + pool_off);
+        pool_off += bytes;
+        pool_peak = std::max(pool_peak, pool_off);
+        return q;
+    }
+    unsigned* tickets(int n) { unsigned* q = ticket_base + ticket_used; ticket_used += (size_t)n; return q; }
+    const TailPlan* tail_of(int prod) const { return (plan && prod >= 0 && prod < (int)plan->size() && (*plan)[prod].on) ? &(*plan)[prod] : nullptr; }
     bool used_split = false;   // a split-storage tensor was allocated: the call needs the split weights (checked after the dry run)
     View T(int B, int H, int W, int C, int dt) {
         if (dt == RS_F16S) used_split = true;
@@ -251,6 +278,7 @@ struct Exec {
             (void)hipEventRecord(e0, st);
         }
         check(rs_igemm_launch(&p, in_dt, out_dt, nz, st), what);
+        if (p.splitk > 1) ++launches;   // (the slices' reduce kernel)
         if (e1) (void)hipEventRecord(e1, st);
     }
     // fused qkv projection + window attention: the projection's FLOPs / compulsory bytes stay in the MFMA-family bookkeeping
@@ -335,6 +363,7 @@ struct rs_engine {
     long long last_igemm_launches = 0, last_gn_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
+    std::vector<TailPlan> tail_plan;   // made by the dry pass of a call, read by its real pass (Exec::plan)
     // UNet
     std::vector<UBlock> in_blocks, out_blocks;
     ResBlockW mid_res1, mid_res2; BasicLayerW mid_swin;
@@ -760,6 +789,11 @@ struct rs_engine {
             if (y.st) {   // statistics for the consuming GroupNorm: only the halo kernel's epilogue produces them
                 if (!x1 && stride == 1 && up == 1 && halo_conv(w, x, y, res)) { p.ystats = y.st; p.ystats_ld = y.stld; }
                 else { ex.err = -3; g_err = "output statistics requested from a conv that does not run on the halo kernel"; return; }
+                if (const TailPlan* t = ex.tail_of(y.st_prod)) {   // ... and that GroupNorm's coefficients too (gn_tail.h)
+                    p.tail.gamma = t->gamma; p.tail.beta = t->beta; p.tail.film = t->film; p.tail.eps = t->eps;
+                    p.tail.coef = (float*)(ex.pool_base + t->coef_off); p.tail.ticket = ex.tickets(y.B);
+                    p.tail.C = t->C; p.tail.groups = 32; p.tail.HW = t->HW;
+                }
             }
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
@@ -779,7 +813,7 @@ struct rs_engine {
     void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res) {
         static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
         const int HW = y.H * y.W;
-        if (!on || ex.trace || !halo_conv(w, x, y, res)) return;
+        if (!on || ex.dbg || !halo_conv(w, x, y, res)) return;
         // one partial set per pixel tile of the kernel variant (256 or 128 pixels of one image); split-K launches: the reduce kernel,
         // in slabs of 256 pixels (or the whole image when it is smaller: the 8 x 8 planes)
         const IGemmParams pp = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
@@ -787,15 +821,15 @@ struct rs_engine {
         if (spx <= 0 || (HW % spx)) return;
         y.stS = HW / spx; y.stld = y.ld;
         y.st = (float*)ex.raw((size_t)y.B * y.stS * y.stld * 2 * sizeof(float));
+        y.st_prod = ex.prod_seq++;
     }
     // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
     // halo kernel the GroupNorm only produces per-(image, channel) affine coefficients and the conv applies them to the RAW tensor
     // in LDS (bit-identical to normalising first); otherwise normalise into a scratch tensor and convolve that
     void gn_silu_conv3(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& Y, float eps, const float* film, const View* res) {
         static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
-        if (fold && !ex.trace && halo_conv(w, X, Y, res)) {
-            float* coef = (float*)ex.raw((size_t)X.B * 2 * X.C * sizeof(float));
-            gn(ex, g, X, X, eps, RS_ACT_NONE, film, coef);
+        if (fold && !ex.dbg && halo_conv(w, X, Y, res)) {
+            const float* coef = gn_coef(ex, g, X, eps, film);
             conv3(ex, w, X, Y, res, 0, coef, RS_ACT_SILU);
             return;
         }
@@ -805,6 +839,31 @@ struct rs_engine {
     }
     void conv1(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
         conv(ex, w, x, nullptr, y, 1, 0, 0, 1, act, res);
+    }
+    // The per-(image, channel) affine [B][2][C] of a GroupNorm whose consumer applies it while loading x (halo conv, fused Swin kernels).
+    // Three ways to get it, cheapest first: the launch that produced x's statistics wrote it already (tail, planned by the dry pass);
+    // ONE statistics launch whose last workgroup per image writes it (x has no producer statistics); or the coefficient kernel over the
+    // producer's partials (RS_GN_TAIL=0, or a producer that is claimed by another GroupNorm).
+    const float* gn_coef(Exec& ex, const GNW& g, const View& x, float eps, const float* film) {
+        static const bool tails = []() { const char* e = getenv("RS_GN_TAIL"); return !(e && e[0] == '0'); }();
+        float* coef = ex.pool((size_t)x.B * 2 * x.C * sizeof(float));
+        const int me = ex.gn_seq++;
+        if (tails && !ex.dbg && x.st && x.st_prod >= 0 && ex.plan) {
+            std::vector<TailPlan>& pl = *ex.plan;
+            if (ex.dry) {
+                if ((int)pl.size() <= x.st_prod) pl.resize(x.st_prod + 1);
+                TailPlan& t = pl[x.st_prod];
+                if (!t.on) {
+                    t.on = true; t.consumer = me; t.gamma = g.gamma; t.beta = g.beta; t.film = film; t.eps = eps; t.C = x.C; t.HW = x.H * x.W;
+                    t.coef_off = (size_t)((char*)coef - ex.pool_base);
+                    ex.ticket_used += (size_t)x.B;   // (drawn by the producer's launch in the real pass)
+                }
+            }
+            const TailPlan* t = ex.tail_of(x.st_prod);
+            if (t && t->consumer == me) return coef;   // written by the producer's tail: nothing to launch
+        }
+        gn(ex, g, x, x, eps, RS_ACT_NONE, film, coef);
+        return coef;
     }
     // `coef` non-null: statistics + affine coefficients only ([B][2][C] floats), y is not written (fused consumer kernels)
     void gn(Exec& ex, const GNW& g, const View& x, const View& y, float eps, int act, const float* film = nullptr, float* coef = nullptr) {
@@ -818,8 +877,11 @@ struct rs_engine {
         S = std::max(1, std::min(S, HW / minpx));
         int S2 = std::max(1, std::min(HW / minpx, std::max(1, tgt2 / std::max(1, x.B))));
         float* partial = (float*)ex.raw((size_t)x.B * S * 32 * 2 * sizeof(float));
+        // coefficient-only without producer statistics: one launch, the statistics kernel's last workgroup per image finishes (gn_tail.h)
+        unsigned* ticket = (coef && !x.st && HW > 256) ? ex.tickets(x.B) : nullptr;
         if (ex.dry) return;
         GNParams p{};
+        p.ticket = ticket;
         p.x = x.p; p.y = y.p; p.gamma = g.gamma; p.beta = g.beta; p.film = film; p.partial = partial;
         p.B = x.B; p.HW = HW; p.C = x.C; p.ldx = x.ld; p.ldy = y.ld; p.S = S; p.groups = 32; p.eps = eps; p.act = act; p.coef = coef;
         if (x.st) { p.cpartial = x.st; p.cp_ld = x.stld; p.S = x.stS; }   // per-channel partials from the producing conv: no statistics pass
@@ -829,9 +891,10 @@ struct rs_engine {
         ++ex.gn_launches;
         hipEvent_t e0, e1;
         Exec::bracket(ex.prof_gn, ex.st, e0, e1);
-        ex.check(rs_groupnorm_launch(&p, x.dt, S2, ex.st), "groupnorm");
+        const int nk = rs_groupnorm_launch(&p, x.dt, S2, ex.st);   // number of kernels launched, or < 0
+        ex.check(nk < 0 ? nk : 0, "groupnorm");
+        if (nk > 1) ex.launches += nk - 1;
         if (e1) (void)hipEventRecord(e1, ex.st);
-        ++ex.launches;
     }
     // models/unet.py:186-206 (use_scale_shift_norm path); eps 1e-5 (basic_ops.py:96 default GroupNorm eps)
     void resblock(Exec& ex, const ResBlockW& r, const View& X, const View& Y, const float* film_row) {
@@ -882,12 +945,12 @@ struct rs_engine {
             static const int gn_fold = []() { const char* v = getenv("RS_GN_FOLD"); return v ? atoi(v) : 1; }();
             // split storage: the same fusion in win_attn_split.hip (RS_ATTN_FUSED_SPLIT=0: separate qkv GEMM, attention, projection GEMM)
             static const int attn_fused_split = []() { const char* v = getenv("RS_ATTN_FUSED_SPLIT"); return v ? atoi(v) : 1; }();
-            const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.trace &&
+            const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.dbg &&
                                   ((attn_fused && X.dt == RS_F16 && s.qkv.wh_frag) || (attn_fused_split && X.dt == RS_F16S && s.qkv.ws_frag && s.proj.ws_frag));
             const bool fold1 = fuse_qkv && gn_fold;
             View n;
-            float* coef1 = nullptr;
-            if (fold1) { coef1 = (float*)ex.raw((size_t)X.B * 2 * E * sizeof(float)); gn(ex, s.n1, e, e, 1e-5f, RS_ACT_NONE, nullptr, coef1); }
+            const float* coef1 = nullptr;
+            if (fold1) coef1 = gn_coef(ex, s.n1, e, 1e-5f, nullptr);
             else { n = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n1, e, n, 1e-5f, RS_ACT_NONE); }
             View qkv;
             if (!fuse_qkv) {
@@ -905,7 +968,7 @@ struct rs_engine {
             // per pass on one box, profiles/r3_negative_results.txt: those passes read tensors that are still resident in the 256 MB
             // Infinity Cache, the epilogue reductions and the many-partial coefficient kernels cost as much)
             static const bool swin_stats = []() { const char* v = getenv("RS_GN_SWIN_STATS"); return v && v[0] == '1'; }();
-            if (fuse_proj && swin_stats && !ex.trace) {
+            if (fuse_proj && swin_stats && !ex.dbg) {
                 e2.stS = (X.H / 8) * (X.W / 8); e2.stld = e2.ld;
                 e2.st = (float*)ex.raw((size_t)X.B * e2.stS * e2.stld * 2 * sizeof(float));
             }
@@ -941,15 +1004,15 @@ struct rs_engine {
             const int Mtok = X.B * X.H * X.W;
             const bool fuse_mlp = mlp_fused && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
                                   s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.w_for(X.dt) && s.fc2.w_for(X.dt);
-            const bool fold2 = fuse_mlp && gn_fold && !ex.trace && (X.H * X.W) % 128 == 0;
+            const bool fold2 = fuse_mlp && gn_fold && !ex.dbg && (X.H * X.W) % 128 == 0;
             View n2;
-            float* coef2 = nullptr;
-            if (fold2) { coef2 = (float*)ex.raw((size_t)X.B * 2 * E * sizeof(float)); gn(ex, s.n2, e2, e2, 1e-5f, RS_ACT_NONE, nullptr, coef2); }
+            const float* coef2 = nullptr;
+            if (fold2) coef2 = gn_coef(ex, s.n2, e2, 1e-5f, nullptr);
             else { n2 = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE); }
             if (fuse_mlp) {
                 e3 = ex.T(X.B, X.H, X.W, E, X.dt);
                 const int HWt = X.H * X.W;
-                if (swin_stats && !ex.trace && HWt % 32 == 0 && Mtok % 32 == 0) {   // consumed by the next block's norm1 (if any)
+                if (swin_stats && !ex.dbg && HWt % 32 == 0 && Mtok % 32 == 0) {   // consumed by the next block's norm1 (if any)
                     e3.stS = HWt / 32; e3.stld = e3.ld;
                     e3.st = (float*)ex.raw((size_t)X.B * e3.stS * e3.stld * 2 * sizeof(float));
                 }
@@ -1083,6 +1146,7 @@ struct rs_engine {
         const rs_unet_config& u = cfg.unet;
         const int n_in = (int)in_blocks.size(), n_out = (int)out_blocks.size();
         const size_t mk0 = ex.mark();
+        ex.pool_off = 0;   // coefficient pool: every slot is consumed within this forward; the next one may reuse them (stream order)
         auto lvH = [&](int level) { return H >> level; };
         auto lvW = [&](int level) { return W >> level; };
         // zero-copy concat buffers, one per output block
@@ -1224,6 +1288,7 @@ struct rs_engine {
     void encode_body(Exec& ex, const View& in_nhwc, float* z_nchw, int dt) {
         const rs_ae_config& a = cfg.ae;
         const size_t mk0 = ex.mark();
+        ex.pool_off = 0;
         const int B = in_nhwc.B;
         View h = ex.T(B, in_nhwc.H, in_nhwc.W, a.ch, dt);
         conv(ex, enc_in, in_nhwc, nullptr, h, 1, 1, 1, 1, 0, nullptr);
@@ -1257,6 +1322,7 @@ struct rs_engine {
     void decode_body(Exec& ex, const float* z_nchw, float zscale, float* img, int32_t* idx_out, int B, int h_, int w_, int force_nq, int dt) {
         const rs_ae_config& a = cfg.ae;
         const size_t mk0 = ex.mark();
+        ex.pool_off = 0;
         View z = ex.T(B, h_, w_, a.embed_dim, RS_F32);
         if (!ex.dry) ex.check(rs_nchw_to_nhwc_launch(z_nchw, z.p, RS_F32, B, a.embed_dim, h_ * w_, z.ld, 0, zscale, ex.st), "z->nhwc");
         View q = z;
@@ -1297,14 +1363,19 @@ struct rs_engine {
     // ---------------------------------------------------------------- run helper (dry sizing pass, then real pass)
     int run(hipStream_t st, const std::function<void(Exec&)>& fn) {
         if (!ready) return fail("weights are not ready (rs_pack_weights / rs_weights_ready not called)");
-        Exec d; d.st = st; d.arena = &arena; d.dry = true; d.keep = debug;
+        Exec d; d.st = st; d.arena = &arena; d.dry = true; d.keep = debug; d.dbg = debug;
+        tail_plan.clear();
+        d.plan = &tail_plan;
         arena.off = 0; arena.peak = 0;
         fn(d);
         if (d.used_split && !(cfg.enable_split && split_ok))
             return fail(!cfg.enable_split ? "split precision requested but the engine was created without enable_split"
                                           : "split precision is not available for these weights: " +
                                                 (split_err.empty() ? std::string("a conv / linear weight with |w| >= 30 or a non-finite value (the packing rank has its name)") : split_err));
-        const size_t need = arena.peak + 4096;
+        // behind the scratch arena: the GroupNorm coefficient pool and the tails' tickets (gn_tail.h), sized by the dry pass
+        const size_t scratch_end = (arena.peak + 255) & ~(size_t)255;
+        const size_t pool_bytes = (d.pool_peak + 255) & ~(size_t)255, ticket_bytes = d.ticket_used * sizeof(unsigned);
+        const size_t need = scratch_end + pool_bytes + ticket_bytes + 4096;
         if (need > arena.cap) {
             (void)hipStreamSynchronize(st);
             if (arena.base) (void)hipFree(arena.base);
@@ -1313,13 +1384,18 @@ struct rs_engine {
             if (hipMalloc((void**)&arena.base, want) != hipSuccess) return fail("hipMalloc of scratch arena failed (" + std::to_string(want) + " bytes)");
             arena.cap = want;
         }
-        Exec r; r.st = st; r.arena = &arena; r.dry = false; r.keep = debug;
+        Exec r; r.st = st; r.arena = &arena; r.dry = false; r.keep = debug; r.dbg = debug;
         if (debug) { trace.clear(); r.trace = &trace; }
+        r.plan = &tail_plan;
+        r.pool_base = arena.base + scratch_end;
+        r.ticket_base = (unsigned*)(arena.base + scratch_end + pool_bytes);
+        if (ticket_bytes && hipMemsetAsync(r.ticket_base, 0, ticket_bytes, st) != hipSuccess) return fail("hipMemsetAsync of the ticket pool failed");
         arena.off = 0; arena.peak = 0;
         r.prof = &prof; prof.used = 0;
         r.prof_gn = &prof_gn; prof_gn.used = 0; prof_gn.on = prof.on;
         fn(r);
-        last_launches = r.launches;
+        if (r.ticket_used != d.ticket_used || r.pool_peak != d.pool_peak) { if (!r.err) { r.err = -4; g_err = "internal: dry and real pass disagree about the GroupNorm tail plan"; } }
+        last_launches = r.launches + (ticket_bytes ? 1 : 0);
         last_flops[0] = r.igemm_flops[0]; last_flops[1] = r.igemm_flops[1]; last_flops[2] = r.igemm_flops[2]; last_igemm_launches = r.igemm_launches;
         last_igemm_bytes = r.igemm_bytes;
         last_igemm_ms = 0.0;
@@ -1824,7 +1900,8 @@ int rs_op_groupnorm(const void* x, void* y, const float* gamma_host, const float
     GNParams p{};
     p.x = x; p.y = y; p.gamma = g; p.beta = bt; p.film = film_dev; p.partial = partial; p.B = B; p.HW = HW; p.C = C; p.ldx = C; p.ldy = C;
     p.S = S; p.groups = groups; p.eps = eps; p.act = act;
-    const int rc = rs_groupnorm_launch(&p, prec, S2, st);
+    const int nk = rs_groupnorm_launch(&p, prec, S2, st);   // kernels launched, or < 0
+    const int rc = nk < 0 ? nk : 0;
     if (rc) fail("groupnorm launch rejected the shape");
     (void)hipStreamSynchronize(st);
     (void)hipFree(g); (void)hipFree(bt); (void)hipFree(partial);

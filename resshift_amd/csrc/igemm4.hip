@@ -28,7 +28,9 @@ namespace {
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IGemmParams p, int HW, int SP) {
     constexpr int PM = Store<TO>::PM;
-    __shared__ float red[16][16][8];
+    // (one LDS array: the reduction scratch [16][16][8], reused by the GroupNorm tail - 2 C + 2 groups floats + the flag word)
+    __shared__ float lds[2 * 1280 + 2 * 32 + 4 > 2048 ? 2 * 1280 + 2 * 32 + 4 : 2048];
+    float (*red)[16][8] = (float (*)[16][8])lds;
     const int tid = threadIdx.x, q = tid & 15, pl = tid >> 4;
     const int S = (HW + SP - 1) / SP;
     const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
@@ -75,15 +77,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IGemmParams p,
         const int nn = blockIdx.y * 64 + tid;
         if (nn < p.Cout) {
             float* dst = p.ystats + (((long long)b * S + sl) * p.ystats_ld + nn) * 2;
-            dst[0] = a; dst[1] = c2;
+            if (p.tail.coef) rs_pub_pair(dst, a, c2);
+            else { dst[0] = a; dst[1] = c2; }
         }
     }
+    // GroupNorm tail (gn_tail.h): the last (slab, channel block) workgroup of image b writes the consuming GroupNorm's coefficients
+    if (p.tail.coef && rs_gn_tail_arrive(p.tail, b, (unsigned*)&lds[2 * 1280 + 2 * 32])) rs_gn_tail_finish<256>(p.tail, b, lds);
 }
 
-int reduce_stats_launch(const IGemmParams& p, int out_dt, hipStream_t st) {
+int reduce_stats_launch(const IGemmParams& p_in, int out_dt, hipStream_t st) {
+    IGemmParams p = p_in;
     const int HW = p.Ho * p.Wo, SP = std::min(HW, 256), S = (HW + SP - 1) / SP;
     if ((p.Cout & 3) || (p.ldy & 3) || (p.res && (p.ldres & 3))) return -2;
     const dim3 grid(p.B * S, (p.Cout + 63) / 64);
+    if (p.tail.coef) {
+        if (p.tail.C > 1280 || p.tail.groups > 32) return -2;   // (the kernel's LDS scratch)
+        p.tail.expected = S * (int)grid.y;
+        p.tail.st0 = p.ystats; p.tail.S0 = S; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
+    }
     if (out_dt == RS_F16) hipLaunchKernelGGL((splitk_reduce_stats_kernel<f16>), grid, dim3(256), 0, st, p, HW, SP);
     else if (out_dt == RS_F16S) hipLaunchKernelGGL((splitk_reduce_stats_kernel<h2s>), grid, dim3(256), 0, st, p, HW, SP);
     else return -2;
@@ -176,14 +187,16 @@ extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC
     if (((size_t)pp->x0 & 15) || ((size_t)pp->y & 15) || ((size_t)pp->res & 15)) return -2;   // 16-byte row pieces: a view whose channel offset is not a multiple of 8
     IGemmParams p = *pp;
     float* const want_stats = p.ystats;
-    if (sk > 1) p.ystats = nullptr;   // slices cannot see the final values: the reduce kernel produces the statistics
+    const GNTail want_tail = p.tail;
+    if (want_tail.coef && !want_stats) return -2;   // a tail finishes statistics this launch produces
+    if (sk > 1) { p.ystats = nullptr; p.tail.coef = nullptr; }   // slices cannot see the final values: the reduce kernel produces the statistics (and carries the tail)
     if (seg == 8 && want_stats && sk == 1) return -2;   // four images per tile: no per-image statistics from the tile epilogue
     int rc;
     if (seg == -4) rc = rs_igemm4_w4_launch(&p, in_dt, BC, st);
     else if (seg) rc = rs_igemm4_seg_launch(&p, in_dt, seg, BC, st);
     else rc = (in_dt == RS_F16S ? launch4_t<true>(p, TW, BC, st) : launch4_t<false>(p, TW, BC, st)) == hipSuccess ? 0 : -1;
     if (rc != 0 || sk == 1) return rc;
-    p.ystats = want_stats;
+    p.ystats = want_stats; p.tail = want_tail;
     return want_stats ? reduce_stats_launch(p, in_dt, st) : rs_splitk_reduce_launch(&p, in_dt, st);
 }
 

@@ -38,6 +38,7 @@
 // optional GroupNorm statistics of the stored output).
 #pragma once
 #include "igemm_common.h"
+#include "gn_tail.h"
 #include <type_traits>
 
 namespace {
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // per-channel statistics of the stored output for the consuming GroupNorm (IGemmParams::ystats): lane (lr, lg) accumulates its
     // 4 channels of every channel fragment over its FP pixel fragments, then the 16 `lr` lanes are reduced with xor-shuffles
     float* const ystats = p.ystats;
+    const bool tail_on = p.tail.coef != nullptr;
     // (LDS: the staging tiles end below 8 * 64 * ROWB <= 106 KB; the partials sit behind them)
     float* const sb = (float*)(smem + NWV * 64 * ROWB);
     // wave-level sum of one (channel fragment, register) column over the 16 pixel lanes -> LDS
@@ -518,9 +520,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             for (int w4 = 0; w4 < WPX; ++w4) { a += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2 + 1]; }
             // (SEG = 16: the tile IS the image; SEG = 8 never produces statistics here - four images per tile)
             float* dst = ystats + ((SEG ? (long long)b : (long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + tid) * 2;
-            dst[0] = a; dst[1] = q;
+            if (tail_on) rs_pub_pair(dst, a, q);   // write-through: another workgroup (the image's last arriver) reads it inside this launch
+            else { dst[0] = a; dst[1] = q; }
         }
     };
+    // GroupNorm tail (gn_tail.h): with IGemmParams::tail the workgroup that publishes the LAST statistics of image b also writes the
+    // consuming GroupNorm's coefficients - the ticket is drawn right behind the statistics (the drain covers only those few stores), the
+    // coefficient work waits until this workgroup's own output tile is on its way
+    unsigned* const tail_flag = (unsigned*)(smem + NWV * 64 * ROWB + NWV * (BC / 2) * 2 * sizeof(float));
+    bool tail_last = false;
     if constexpr (SPLIT) {
         // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             }
         }
         if (ystats) stats_out();
+        if (ystats && tail_on) tail_last = rs_gn_tail_arrive(p.tail, b, tail_flag);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -655,6 +664,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
         };
         if (res_ok) run(std::true_type{}); else run(std::false_type{});
         if (ystats) stats_out();
+        if (ystats && tail_on) tail_last = rs_gn_tail_arrive(p.tail, b, tail_flag);
         RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;
@@ -662,6 +672,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             if (n >= p.Cout) continue;
             *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
+    }
+    if (tail_last) {   // (workgroup-uniform) every wave is done with its staging tile behind this barrier: the LDS is free
+        __syncthreads();
+        rs_gn_tail_finish<NT>(p.tail, b, (float*)smem);
     }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 3] = clock64();
@@ -701,6 +715,12 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    if (p.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every (pixel tile, channel tile) workgroup of an image arrives once
+        if (!p.ystats || sk > 1 || SEG == 8) return hipErrorInvalidValue;   // (split-K slices / four-image tiles: the reduce kernel carries the tail)
+        const int per_image = SEG == 16 ? 1 : (p.Ho / TH) * (p.Wo / TW);
+        p.tail.expected = per_image * ((p.Cout + BC - 1) / BC);
+        p.tail.st0 = p.ystats; p.tail.S0 = per_image; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
+    }
     {   // A/B knob: RS_IG4_EARLY_GN=1 lets the GroupNorm pass of chunk c + 1 ride on taps 7 / 8 of chunk c
         static const bool early = []() { const char* v = getenv("RS_IG4_EARLY_GN"); return v && v[0] == '1'; }();   // measured: no gain (profiles/r3_igemm4_early_gn.txt)
         p.dbg = early ? 0 : 16;

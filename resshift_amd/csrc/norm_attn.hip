@@ -8,6 +8,7 @@
 //              (swin_transformer.py:35-63,252-275) folded into the load/store addressing.
 //   Row softmax: ldm/modules/diffusionmodules/model.py:193 (AE mid-block attention).
 #include "common.h"
+#include "gn_tail.h"
 #include <type_traits>
 
 namespace {
@@ -15,8 +16,10 @@ namespace {
 // ---------------------------------------------------------------- GroupNorm
 // stats: grid (S, B).  Thread (pp, j) owns 8-channel chunk j and walks pixels pp, pp+PP, ...
 // Deterministic: per-thread partial sums go to LDS, one thread per group reduces them in a fixed order.
+// `tail.coef` set (coefficient-only GroupNorms of tensors whose producer leaves no statistics): the partials are published write-through
+// and the last workgroup of every image turns them into the affine coefficients (gn_tail.h) - statistics + coefficients in ONE launch.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p, GNTail tail) {
     __shared__ float red[256][17];
     const int s = blockIdx.x, b = blockIdx.y;
     const int nchunk = p.C >> 3;
@@ -67,7 +70,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p) {
                 q += red[t][8 + (c & 7)];
             }
         float* out = p.partial + (((long long)b * p.S + s) * p.groups + tid) * 2;
-        out[0] = a; out[1] = q;
+        if (tail.coef) rs_pub_pair(out, a, q);
+        else { out[0] = a; out[1] = q; }
+    }
+    if (tail.coef) {
+        // (red: 256 x 17 floats, free behind the barrier inside arrive; the coefficient scratch needs 2 C + 2 groups <= 4160 of them,
+        // the flag word sits behind that)
+        if (rs_gn_tail_arrive(tail, b, (unsigned*)&red[255][16])) rs_gn_tail_finish<256>(tail, b, &red[0][0]);
     }
 }
 
@@ -161,22 +170,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
         float a = 0.f, q = 0.f;
         for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * p.groups + tid) * 2]; q += ps[(sl * p.groups + tid) * 2 + 1]; }
         const float n = (float)cpg * (float)p.HW;
-        const float mean = a / n;
-        float var = q / n - mean * mean;
-        var = fmaxf(var, 0.f);
-        gm[tid] = mean;
-        gr[tid] = 1.0f / sqrtf(var + p.eps);
+        rs_gn_group(a, q, n, p.eps, gm[tid], gr[tid]);   // (gn_tail.h: the tails use the same expressions)
     }
     __syncthreads();
     for (int c = tid; c < p.C; c += 256) {
         const int g = c / cpg;
-        float a = p.gamma[c] * gr[g];
-        float bb = p.beta[c] - gm[g] * a;
-        if (p.film) {
-            const float sc = 1.0f + p.film[c];
-            a *= sc;
-            bb = fmaf(bb, sc, p.film[p.C + c]);
-        }
+        float a, bb;
+        rs_gn_channel(p.gamma[c], p.beta[c], gm[g], gr[g], p.film, c, p.C, a, bb);
         ca[c] = a; cb[c] = bb;
     }
     __syncthreads();
@@ -243,20 +243,13 @@ __device__ __forceinline__ void gn_fused_body(const GNParams& p, int SC, float (
             q += cb[(c >> 3) * 16 + 8 + (c & 7)];
         }
         const float n = (float)cpg * (float)p.HW;
-        gmean = a / n;
-        const float var = fmaxf(q / n - gmean * gmean, 0.f);
-        grstd = 1.0f / sqrtf(var + p.eps);
+        rs_gn_group(a, q, n, p.eps, gmean, grstd);
     }
     __syncthreads();                              // column sums consumed: ca / cb now take the affine coefficients
     if (tid < gps) {
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            float ga = p.gamma[cs + c] * grstd;
-            float be = p.beta[cs + c] - gmean * ga;
-            if (p.film) {
-                const float sc = 1.0f + p.film[cs + c];
-                ga *= sc;
-                be = fmaf(be, sc, p.film[p.C + cs + c]);
-            }
+            float ga, be;
+            rs_gn_channel(p.gamma[cs + c], p.beta[cs + c], gmean, grstd, p.film, cs + c, p.C, ga, be);
             ca[c] = ga; cb[c] = be;
         }
     }
@@ -310,9 +303,13 @@ template <int MAXI, int NT> int gn_fused_slice(const GNParams& p) {
 
 }  // namespace
 
+// Returns the number of kernels launched (1 or 2), or a negative error code.
+// `pp->ticket` (with `coef`): coefficient-only GroupNorm of a tensor without producer statistics in ONE launch - the statistics kernel's
+// last workgroup per image writes the coefficients (gn_tail.h).  RS_GN_TAIL=0 keeps the two launches (A/B runs).
 extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, hipStream_t st) {
     const GNParams& p = *pp;
     if ((p.C % 8) || (p.C % p.groups) || p.C / 8 > 256 || p.groups > 256 || (p.ldx % 8) || (p.ldy % 8)) return -2;
+    GNTail tail{};
     // small planes: one fused launch (RS_GN_FUSED=0 keeps the two-kernel path for A/B runs)
     static const bool fused_on = []() { const char* e = getenv("RS_GN_FUSED"); return !(e && e[0] == '0'); }();
     // measured at B=32 (8-step bench, ms/step): fused up to 256 px 174.1, up to 1024 px 174.1, up to 4096 px 176.8 (too few,
@@ -326,7 +323,7 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
             if (dt == RS_F16) hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI, 256>), g, dim3(256), 0, st, p, SC);
             else if (dt == RS_F16S) hipLaunchKernelGGL((gn_fused_kernel<h2s, MAXI, 256>), g, dim3(256), 0, st, p, SC);
             else hipLaunchKernelGGL((gn_fused_kernel<float, MAXI, 256>), g, dim3(256), 0, st, p, SC);
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+            return hipGetLastError() == hipSuccess ? 1 : -1;
         }
     } else if (fused_on && dt == RS_F16 && p.HW <= fused_max && !p.cpartial) {
         // 32x32 / 64x64 planes in fp16: 1024 threads hold up to 20 items (80 VGPRs) each; the tensor is read once instead of twice
@@ -334,23 +331,29 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
         const int SC = gn_fused_slice<MAXI, 1024>(p);
         if (SC > 0) {
             hipLaunchKernelGGL((gn_fused_kernel<f16, MAXI, 1024>), dim3(p.C / SC, p.B), dim3(1024), 0, st, p, SC);
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+            return hipGetLastError() == hipSuccess ? 1 : -1;
         }
     }
     dim3 g1(p.S, p.B), g2(p.coef ? 1 : apply_slabs, p.B);
     const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
     const bool need_stats = p.cpartial == nullptr;   // (else the producing conv's epilogue already left per-channel partial sums)
-    if (dt == RS_F16) {
-        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p);
-        hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
-    } else if (dt == RS_F16S) {
-        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<h2s>), g1, dim3(256), 0, st, p);
-        hipLaunchKernelGGL((gn_apply_kernel<h2s>), g2, dim3(256), lds, st, p);
-    } else {
-        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p);
-        hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), lds, st, p);
+    static const bool tail_on = []() { const char* e = getenv("RS_GN_TAIL"); return !(e && e[0] == '0'); }();
+    const bool use_tail = tail_on && need_stats && p.coef && p.ticket;
+    if (use_tail) {
+        tail.gamma = p.gamma; tail.beta = p.beta; tail.film = p.film; tail.coef = p.coef; tail.ticket = p.ticket; tail.expected = p.S;
+        tail.C = p.C; tail.groups = p.groups; tail.HW = p.HW; tail.eps = p.eps; tail.stg = p.partial; tail.Sg = p.S;
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (dt == RS_F16) {
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<f16>), g1, dim3(256), 0, st, p, tail);
+        if (!use_tail) hipLaunchKernelGGL((gn_apply_kernel<f16>), g2, dim3(256), lds, st, p);
+    } else if (dt == RS_F16S) {
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<h2s>), g1, dim3(256), 0, st, p, tail);
+        if (!use_tail) hipLaunchKernelGGL((gn_apply_kernel<h2s>), g2, dim3(256), lds, st, p);
+    } else {
+        if (need_stats) hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, st, p, tail);
+        if (!use_tail) hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), lds, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? (need_stats && !use_tail ? 2 : 1) : -1;
 }
 
 // ---------------------------------------------------------------- window attention
