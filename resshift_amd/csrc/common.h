@@ -253,6 +253,8 @@ struct GNParams {
                          // so that a consumer kernel can apply y = x * scale + shift while it loads x (fused Swin kernels)
     const float* cpartial;   // non-null: per-channel partial sums [B][S][cp_ld][2] written by the producing conv's epilogue
     int cp_ld;               // (IGemmParams::ystats) replace `partial`; no statistics kernel runs
+    const float* cpartial2;  // non-null: the tensor is a channel concatenation (models/unet.py:891) whose halves come from two producers -
+    int cp2_ld, cp2_S, cp_n0;   // `cpartial` (S sets) covers channels [0, cp_n0), `cpartial2` ([B][cp2_S][cp2_ld][2]) channels [cp_n0, C)
     unsigned* ticket;        // non-null (with `coef`, without `cpartial`): [B] zeroed arrival counters - the statistics kernel's last
                              // workgroup per image writes the coefficients itself (gn_tail.h), no second launch
 };

@@ -103,6 +103,9 @@ int reduce_stats_launch(const IGemmParams& p_in, int out_dt, hipStream_t st) {
 
 }  // namespace
 
+// the same finish for the split-K launches of the generic kernels (igemm_split.hip)
+extern "C" int rs_splitk_reduce_stats_launch(const IGemmParams* p, int out_dt, hipStream_t st) { return reduce_stats_launch(*p, out_dt, st); }
+
 // Which launches take the halo kernel, and how: fp16 or split storage in / out (the same one), one source, 3x3 stride 1 pad 1 without
 // the folded upsample, input channels in multiples of 32, output channels in multiples of 8 with a channel tile of at most 192, no
 // batching.  Geometry: planes that tile by 4 x 64 or 8 x 32 output pixels with enough tiles to fill the chip (SEG = 0, no split-K), or

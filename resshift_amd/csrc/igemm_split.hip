@@ -14,10 +14,12 @@
 //     residual (split storage), then either fp32 output or a fresh (hi, lo) split, transposed through LDS into 16-byte
 //     stores.
 #include "igemm_common.h"
+#include "gn_tail.h"
 #include <algorithm>
 #include <type_traits>
 
 extern "C" int rs_splitk_reduce_launch(const IGemmParams* p, int out_dt, hipStream_t st);
+extern "C" int rs_splitk_reduce_stats_launch(const IGemmParams* p, int out_dt, hipStream_t st);   // igemm4.hip: reduce + statistics (+ GroupNorm tail)
 
 namespace {
 
@@ -397,7 +399,43 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
     if (p.act == RS_ACT_GELU) finish_all(std::integral_constant<int, RS_ACT_GELU>{});
     else if (p.act == RS_ACT_SILU) finish_all(std::integral_constant<int, RS_ACT_SILU>{});
     else finish_all(std::integral_constant<int, RS_ACT_NONE>{});
+    bool tail_last = false;
+    int tail_img = 0;
     if constexpr (std::is_same<TO, h2s>::value) {
+        // Per-channel statistics of the output for the GroupNorm that consumes it (IGemmParams::ystats, [B][HW / BP][ystats_ld][2]; the
+        // launcher guarantees whole tiles inside one image: M % BP == 0, HW % BP == 0): the stored (hi, lo) pair reproduces the value to
+        // 2^-23, so the sums are taken from the registers - as in the halo kernel's epilogue (igemm4_kernel.h), same reduction: the 16
+        // pixel lanes by xor-shuffles, the pixel-waves through LDS in a fixed order, no atomics.  With IGemmParams::tail the workgroup
+        // that completes an image's statistics also writes the consuming GroupNorm's coefficients (gn_tail.h).
+        if (p.ystats) {
+            constexpr int WT = (BP / WPN) * ((BC / 2) * 2 + 16);
+            float* const sb = (float*)(smem + NWV * 2 * WT);         // behind the staging tiles: [NWV][BC / 2][2]
+            unsigned* const tflag = (unsigned*)(sb + NWV * (BC / 2) * 2);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = 0.f, q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) { a += am[i][j][r]; q = fmaf(am[i][j][r], am[i][j][r], q); }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                    if (lr == 0) { sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
+                }
+            __syncthreads();
+            const int hw = p.Ho * p.Wo;
+            tail_img = m0 / hw;
+            if (tid < BC && n0 + tid < p.Cout) {
+                const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < WPN; ++w4) { a += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2 + 1]; }
+                float* dst = p.ystats + (((long long)tail_img * (hw / BP) + (m0 - tail_img * hw) / BP) * p.ystats_ld + n0 + tid) * 2;
+                if (p.tail.coef) rs_pub_pair(dst, a, q);
+                else { dst[0] = a; dst[1] = q; }
+            }
+            if (p.tail.coef) tail_last = rs_gn_tail_arrive(p.tail, tail_img, tflag);
+        }
         f16* y = (f16*)p.y + 2 * z * p.bs_y;
         // wave tile (BP/WPN rows x BC/2 channels) staged twice (hi, lo) with a padded row pitch, then 16-byte stores
         constexpr int ROWB = (BC / 2) * 2 + 16;
@@ -451,6 +489,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             }
         }
     }
+    if (tail_last) {   // (workgroup-uniform) every wave is done with its staging tile behind this barrier: the LDS is free
+        __syncthreads();
+        rs_gn_tail_finish<64 * NWV>(p.tail, tail_img, (float*)smem);
+    }
     RS_IGS_STAMP(3);
 }
 
@@ -473,8 +515,28 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
         p.sh_howo = pow2 ? __builtin_ctz(howo) : -1;
         p.sh_wo = pow2 ? __builtin_ctz(p.Wo) : -1;
     }
+    // output statistics (+ GroupNorm tail): from this kernel's epilogue, or - split-K - from the reduce kernel that finishes the slabs
+    float* const want_stats = p.ystats;
+    const GNTail want_tail = p.tail;
+    if (want_tail.coef && !want_stats) return hipErrorInvalidValue;
+    if (want_stats) {
+        const int hw = p.Ho * p.Wo;
+        if (!std::is_same<TO, h2s>::value || nz != 1) return hipErrorInvalidValue;
+        if (p.splitk > 1) { p.ystats = nullptr; p.tail.coef = nullptr; }
+        else {
+            if ((p.M % BP) || (hw % BP)) return hipErrorInvalidValue;   // whole tiles inside one image (rs_igemm_split_stats_px)
+            if (p.tail.coef) {
+                p.tail.expected = (hw / BP) * ((p.Cout + BC - 1) / BC);
+                p.tail.st0 = p.ystats; p.tail.S0 = hw / BP; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
+            }
+        }
+    }
     hipLaunchKernelGGL((igemm_split_kernel<TO, BP, BC, NWV, PIPE, ABL>), dim3(tiles, 1, p.splitk > 1 ? p.splitk : nz), dim3(64 * NWV), lds, st, p);
-    if (p.splitk > 1 && rs_splitk_reduce_launch(&p, std::is_same<TO, h2s>::value ? RS_F16S : RS_F32, st) != 0) return hipErrorLaunchFailure;
+    if (p.splitk > 1) {
+        p.ystats = want_stats; p.tail = want_tail;
+        const int out_dt = std::is_same<TO, h2s>::value ? RS_F16S : RS_F32;
+        if ((want_stats ? rs_splitk_reduce_stats_launch(&p, out_dt, st) : rs_splitk_reduce_launch(&p, out_dt, st)) != 0) return hipErrorLaunchFailure;
+    }
     return hipGetLastError();
 }
 
@@ -536,6 +598,18 @@ extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC) {
     *BC = best;
     const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + best - 1) / best) * nz;
     *BP = (tiles128 < 256) ? 64 : 128;
+}
+
+// pixels per statistics slab of an igemm_split launch that is asked for IGemmParams::ystats (0: it cannot produce them): the pixel tile,
+// or - split-K launches, whose reduce kernel produces them - 256 consecutive pixels / the whole small image (as rs_igemm4_stats_px)
+extern "C" int rs_igemm_split_stats_px(const IGemmParams* pp, int splitk) {
+    const IGemmParams& p = *pp;
+    if (p.C1 != 0 || (p.Cout & 3) || (p.ldy & 3)) return 0;
+    const int hw = p.Ho * p.Wo;
+    if (splitk > 1) return (hw > 256 && (hw % 256)) ? 0 : std::min(hw, 256);
+    int BP, BC;
+    rs_igemm_split_pick(p.M, p.Cout, 1, &BP, &BC);
+    return ((p.M % BP) || (hw % BP)) ? 0 : BP;
 }
 
 // in: split storage; out_dt: RS_F16S or RS_F32.  Single source only (C1 == 0), C0 / ld0 / Ktot multiples of 8.

@@ -143,9 +143,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNParams p) {
         // slice) walking cpg strided pairs per set made this launch as long as the statistics pass it replaces.)
         float* chs = ca;               // [C][2] scratch in the coefficient arrays (2 * C floats, rewritten below)
         for (int c = tid; c < p.C; c += 256) {
-            const float* in = p.cpartial + (((long long)b * p.S) * p.cp_ld + c) * 2;
+            // (two producers: the second one's partials cover the channels from cp_n0 on - same loop as the tails', gn_tail.h)
+            const bool s0 = !p.cpartial2 || c < p.cp_n0;
+            const float* in = s0 ? p.cpartial + (((long long)b * p.S) * p.cp_ld + c) * 2 : p.cpartial2 + (((long long)b * p.cp2_S) * p.cp2_ld + (c - p.cp_n0)) * 2;
+            const int S = s0 ? p.S : p.cp2_S;
+            const long long step = 2ll * (s0 ? p.cp_ld : p.cp2_ld);
             float a = 0.f, q = 0.f;
-            for (int s2 = 0; s2 < p.S; ++s2) { const float2 v = *(const float2*)(in + (long long)s2 * p.cp_ld * 2); a += v.x; q += v.y; }
+            for (int s2 = 0; s2 < S; ++s2) { const float2 v = *(const float2*)(in + s2 * step); a += v.x; q += v.y; }
             chs[2 * c] = a; chs[2 * c + 1] = q;
         }
         __syncthreads();

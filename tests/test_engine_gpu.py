@@ -495,6 +495,34 @@ def test_fused_swin_paths_match_unfused(gpu, tmp_path):
     assert err < 5e-3
 
 
+@pytest.mark.parametrize("prec", ["fp16", "split"])
+def test_groupnorm_tails_change_no_bit(gpu, tmp_path, prec):
+    """Round 4 (gn_tail.h): the launch that completes a tensor's statistics - the halo conv's epilogue, the split-K reduce, the
+    statistics kernel itself - also writes the coefficients of the GroupNorm that consumes it (models/basic_ops.py:15-17,89-96,
+    models/unet.py:198-202), instead of a coefficient kernel of its own.  Same sums, same order, same expressions: RS_GN_TAIL=0 (one
+    launch per coefficient set, as in round 3) must give the same bits on a full-size UNet forward at a batch that takes the halo
+    kernel on every level, twice in a row (fresh tickets, fresh plan per call) - and the tails must remove launches."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(tag, **env):
+        out = tmp_path / f"{tag}.pt"
+        e = dict(os.environ, RS_TEST_META="1", RS_TEST_PREC=prec, RS_TEST_B="16", **{k: str(v) for k, v in env.items()})
+        subprocess.run([sys.executable, os.path.join(here, "_unet_once.py"), str(out)], check=True, env=e, timeout=600)
+        return torch.load(out)
+
+    tail = run("tail")
+    plain = run("plain", RS_GN_TAIL=0)
+    assert torch.isfinite(tail["out"]).all()
+    assert torch.equal(tail["out"], tail["out2"]), "the second call differs from the first (stale tickets / coefficients?)"
+    assert torch.equal(tail["out"], plain["out"]), (tail["out"] - plain["out"]).abs().max().item()
+    print(f"{prec}: kernel launches per UNet forward {plain['launches']} -> {tail['launches']}")
+    assert tail["launches"] <= plain["launches"] - 40
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 2: parity at the headline batch size, the precision policies the bench reports, real pixels, forced VQ indices,
 # timestep respacing.

@@ -357,3 +357,28 @@ def test_bench_launcher_pieces(monkeypatch):
            "sys.argv = ['bench.py', '--gpus', '2']; import runpy; runpy.run_path(%r, run_name='__main__')" % os.path.join(H.ROOT, "bench.py"))
     r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refused" in r.stderr
+
+
+@pytest.mark.parametrize("cname,B,prec", [("realsr_swinunet_realesrgan256", 32, 2), ("realsr_swinunet_realesrgan256", 4, 0),
+                                          ("inpaint_lama256_imagenet", 16, 2), ("faceir_gfpgan512_lpips", 2, 2)])
+def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
+    """Round 4: the GroupNorm tail plan (resshift_amd/csrc/gn_tail.h, engine.hip: TailPlan) is made by the engine's dry sizing pass and
+    executed by its real pass; the two walk the same control flow and must agree about every pool they size: coefficient pool, tickets,
+    producer and GroupNorm sequence numbers - and every planned tail must be attached to its producer's launch.  RS_FAKE_DEVICE=1 lets the
+    real pass run on a host-memory arena in this GPU-less container (every launch fails, the bookkeeping does not).  Also pins the
+    launch diet of the round: <= 3 000 kernel launches per batch-32 parity pass (4 609)."""
+    import re
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RS_FAKE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "_fake_device_plumbing.py"), cname, str(B), str(prec)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    m = re.search(r"dry: tickets (\d+) pool (\d+) prod (\d+) gn (\d+) \| real: tickets (\d+) pool (\d+) prod (\d+) gn (\d+) launches (\d+)", r.stderr)
+    assert m, (r.stdout[-500:], r.stderr[-1500:])
+    v = [int(x) for x in m.groups()]
+    assert v[:4] == v[4:8], v
+    assert "never attached" not in r.stderr and "disagree" not in r.stdout, (r.stdout[-500:], r.stderr[-500:])
+    assert v[0] > 0 and v[1] > 0          # tails were planned at all
+    if cname.startswith("realsr") and B == 32 and prec == 2:
+        assert v[8] <= 3000, v[8]
