@@ -201,9 +201,18 @@ def main():
     def load_fn():
         return random_state_dict(uspec, seed=1), random_state_dict(ae_param_spec(aep), seed=2)
 
-    log("building models + packing weights")
+    # the engine packs (and broadcasts) only the weight forms this run will ask for: the headline policy's, the secondary policy's, fp32
+    # only with --exact-leg
+    forms = set(policy_args(args.precision, steps)[0]) | set(policy_args(args.precision, steps)[1:])
+    if not args.no_secondary:
+        forms |= {"fp16", "split"}
+    if args.mixed_leg:
+        forms |= {"fp16", "split"}
+    if args.exact_leg:
+        forms.add("fp32")
+    log(f"building models + packing weights ({sorted(forms)})")
     t0 = time.time()
-    eng = sharding.build_engine_with_broadcast(model, ae, load_fn, rank, world)
+    eng = sharding.build_engine_with_broadcast(model, ae, load_fn, rank, world, precisions=forms)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
     log(f"weights ready in {setup_s:.1f}s")
@@ -520,6 +529,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cname}: batch {B}/GPU x {world} GPU, {cdesc}, random-init weights",
                        "precision_policy": args.precision, "kernel_launches_per_step": launches, "weight_setup_s": round(setup_s, 2),
+                       "weight_forms_packed": sorted(forms), "weight_blob_mb": round(eng.weight_blob().numel() / 1e6, 1),
                        "parallelism": f"dp{world} (batch sharded, one RCCL weight broadcast, no data-path collective)"},
             "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                       "backend": dist.get_backend() if dist.is_initialized() else None,

@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--config", nargs="+", default=["realsr"])
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--modes", nargs="+", default=["fp16", "split3", "fp8cross"])
+    ap.add_argument("--inputs", default="synthetic", choices=["synthetic", "real"],
+                    help="real: the reference's own validation inputs testdata/Val_SR/lq (tests/golden/val_sr_lq.npz) - smooth natural images, on which the random-init "
+                         "sampler trajectory amplifies a perturbation ~20 dB more than on uniform noise (tests/test_engine_gpu.py: test_fp16_error_on_natural_images_...)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_fp8_cross_study.json"))
     args = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -152,6 +155,12 @@ def main():
         sf = int(dp.get("sf", 4))
         hz, cz, B = lr * sf // f, int(aep["embed_dim"]), args.images
         y = torch.rand(32 if cname != "faceir" else 16, 3, lr, lr, generator=g)[:B] * 2 - 1
+        if args.inputs == "real":
+            import numpy as np
+
+            assert lr == 64, "the bundled validation images are 64 x 64"
+            lq = np.load(os.path.join(ROOT, "tests", "golden", "val_sr_lq.npz"))["lq"][:B].astype(np.float32)
+            y = (torch.from_numpy(lq).permute(0, 3, 1, 2).contiguous() / 255.0 - 0.5) / 0.5   # datapipe/datasets.py:59-63
         noise = torch.randn(steps + 1, B, cz, hz, hz, generator=g)
         mask = (torch.rand(B, 1, lr, lr, generator=g) > 0.7).float() * 2 - 1 if up.get("cond_mask", False) else None
         nz = [noise[k] for k in range(steps + 1)]
@@ -166,13 +175,13 @@ def main():
             img, aux = oc.sample_loop(usd, up, asd, aep, dp, y, nz, mask=mask, return_aux=True)
             same = aux["indices"].reshape(B, -1) == ir
             per = [psnr(img[i].clamp(-1, 1), ref[i].clamp(-1, 1), 2.0) for i in range(B)]
-            row = {"config": cname, "mode": mode, "images": B, "latent_psnr_db": round(psnr(aux["z_final"], zr, (zr.max() - zr.min()).item()), 1),
+            row = {"config": cname, "mode": mode, "images": B, "inputs": args.inputs, "latent_psnr_db": round(psnr(aux["z_final"], zr, (zr.max() - zr.min()).item()), 1),
                    "vq_code_agreement": round(same.float().mean().item(), 5), "vq_code_agreement_worst_image": round(same.float().mean(1).min().item(), 5),
                    "image_psnr_db": round(psnr(img.clamp(-1, 1), ref.clamp(-1, 1), 2.0), 1), "image_psnr_db_worst_image": round(min(per), 1),
                    "seconds": round(time.time() - t0)}
             row["meets_criterion"] = bool(row["image_psnr_db_worst_image"] >= 60.0 and row["vq_code_agreement_worst_image"] >= 0.999)
             print(row, flush=True)
-            results["runs"] = [r for r in results["runs"] if not (r["config"] == cname and r["mode"] == mode and r["images"] == B)] + [row]
+            results["runs"] = [r for r in results["runs"] if not (r["config"] == cname and r["mode"] == mode and r["images"] == B and r.get("inputs", "synthetic") == args.inputs)] + [row]
             with open(args.out, "w") as fh:
                 json.dump(results, fh, indent=1)
     MODE = "exact"

@@ -71,6 +71,22 @@ struct RsAttrFlags {   // "hipFuncSetAttribute done on this device?" of one kern
 #define RS_STAGING_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 
+// Sum over the 16 lanes of a row (lanes 16 r .. 16 r + 15 of the wave), result in every lane: four v_add_f32 with a DPP operand (quad
+// permutes, then row_half_mirror and row_mirror - once the four lanes of a quad agree, mirroring pairs the same partners as the xor-4 /
+// xor-8 steps of a butterfly, so the operands of every addition - and the bits of the result - are those of the __shfl_xor(1, 2, 4, 8)
+// butterfly this replaces).  __shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip per step - 640 of them per wave in the halo
+// kernel's statistics epilogue.
+template <int CTRL> __device__ __forceinline__ float rs_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float rs_sum16(float v) {
+    v += rs_dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += rs_dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += rs_dpp_f32<0x141>(v);   // row_half_mirror      (the other quad of the 8)
+    v += rs_dpp_f32<0x140>(v);   // row_mirror           (the other 8 of the 16)
+    return v;
+}
+
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float rs_silu(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (nn.GELU() default; reference models/swin_transformer.py:18)

@@ -150,6 +150,7 @@ struct ConvW {
     // split: 1 KB of hi then 1 KB of lo per block and k step), so that a wave's A-operand fragment is ONE contiguous 1 KB read
     void* wh_frag = nullptr; void* ws_frag = nullptr;
     bool direct = false;
+    int idx = -1;   // position in rs_engine::big_w (per-layer "|w| >= 30" flags, see there)
     const void* w_for(int dt) const { return dt == RS_F16 ? wh : (dt == RS_F16S ? ws : wf); }
     const void* w_frag_for(int dt) const { return dt == RS_F16 ? wh_frag : (dt == RS_F16S ? ws_frag : nullptr); }
 };
@@ -367,6 +368,14 @@ struct rs_engine {
     // ranks that receive the blob by broadcast know it too.
     std::string split_err;
     bool split_ok = true;
+    // ... and a layer whose weights reach |w| >= 30 is not a reason to refuse the policy: only the kernels that scale the hi fragment by
+    // 2^11 (the halo conv, the fused split Swin kernels) cannot take it, the generic split kernel (igemm_split.hip: two accumulators, no
+    // scaling) can.  One flag byte per conv / linear in build order, written into the blob by the packing rank (it travels with the
+    // broadcast) and read back by rs_weights_ready; halo_conv() / basiclayer() route a flagged layer to the generic kernels.
+    std::vector<unsigned char> big_w;
+    int conv_count = 0;
+    unsigned char* big_w_dev = nullptr;
+    bool big(const ConvW& c) const { return c.idx >= 0 && c.idx < (int)big_w.size() && big_w[c.idx] != 0; }
     Arena arena;
     long long last_launches = 0;
     Exec::Prof prof, prof_gn;
@@ -414,6 +423,9 @@ struct rs_engine {
     // not chunk aligned.
     ConvW add_conv(const std::string& prefix, int Cin, int Cout, int KH, int KW, bool has_bias = true, bool force_direct = false) {
         ConvW c; c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW;
+        c.idx = conv_count++;
+        if ((int)big_w.size() < conv_count) big_w.resize(conv_count, 0);
+        const int cidx = c.idx;
         c.direct = force_direct;
         c.CinP = c.direct ? Cin : (Cin + 7) / 8 * 8;
         const int CinP = c.CinP;
@@ -454,8 +466,10 @@ struct rs_engine {
                             for (int t = 0; t < KH * KW; ++t) {
                                 f16 h, l;
                                 const float wv = w[((size_t)co * Cin + ci) * KH * KW + t];
-                                // (the halo kernel scales the hi fragment by 2^11 in fp16: exact below 32)
-                                if (!(std::fabs(wv) < 30.0f) && split_err.empty()) split_err = "split precision needs |weight| < 30: " + wkey;
+                                // (the halo kernel and the fused Swin kernels scale the hi fragment by 2^11 in fp16: exact below 32 - a layer
+                                // beyond that runs on the generic split kernel; a non-finite weight rules the policy out)
+                                if (!std::isfinite(wv) || std::fabs(wv) > 60000.0f) { if (split_err.empty()) split_err = "split precision needs finite fp16-range weights: " + wkey; }
+                                else if (!(std::fabs(wv) < 30.0f)) big_w[cidx] = 1;
                                 rs_split(wv, h, l);
                                 const size_t k = (size_t)t * CinP + ci;
                                 o[(size_t)co * 2 * K + k] = h;
@@ -725,8 +739,12 @@ struct rs_engine {
         split_err.clear();
         if (fill) blob.staging.assign(blob_bytes, 0);
         (void)blob.add(256, [](char*) {});   // header: word 0 = flags (bit 0: split weights usable), written by rs_pack_weights
+        conv_count = 0;
+        if (fill) std::fill(big_w.begin(), big_w.end(), 0);
         if (cfg.has_unet) build_unet();
         if (cfg.has_ae) build_ae();
+        // (the fillers run in order: by the time this one copies the table every split-weight filler has set its flag)
+        big_w_dev = (unsigned char*)blob.add((size_t)conv_count, [&](char* dst) { memcpy(dst, big_w.data(), (size_t)conv_count); });
         return (blob.off + 255) & ~(size_t)255;
     }
 
@@ -751,6 +769,7 @@ struct rs_engine {
     // slices over the stage sequence, igemm4_kernel.h; `seg`: its tile geometry, 8 = four 8 x 8 images per tile)
     bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res, int* sk = nullptr, int* seg = nullptr) const {
         if (w.direct || (x.dt != RS_F16 && x.dt != RS_F16S) || y.dt != x.dt || x.C != w.CinP) return false;
+        if (x.dt == RS_F16S && big(w)) return false;   // |w| >= 30: no 2^11 scaling of the hi fragment - the generic split kernel takes it
         const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
         int tw, bc, sg = 0, k = 1;
         if (!rs_igemm4_plan(&p, x.dt, y.dt, 1, &tw, &bc, &sg, &k)) return false;
@@ -976,7 +995,8 @@ struct rs_engine {
             static const int gn_fold = []() { const char* v = getenv("RS_GN_FOLD"); return v ? atoi(v) : 1; }();
             // split storage: the same fusion in win_attn_split.hip (RS_ATTN_FUSED_SPLIT=0: separate qkv GEMM, attention, projection GEMM)
             static const int attn_fused_split = []() { const char* v = getenv("RS_ATTN_FUSED_SPLIT"); return v ? atoi(v) : 1; }();
-            const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.dbg &&
+            const bool big_attn = X.dt == RS_F16S && (big(s.qkv) || big(s.proj)), big_mlp = X.dt == RS_F16S && (big(s.fc1) || big(s.fc2));   // (|w| >= 30: unfused path)
+            const bool fuse_qkv = rs_win_attn_qkv_supported(heads, E) && s.bias_n && !ex.dbg && !big_attn &&
                                   ((attn_fused && X.dt == RS_F16 && s.qkv.wh_frag) || (attn_fused_split && X.dt == RS_F16S && s.qkv.ws_frag && s.proj.ws_frag));
             const bool fold1 = fuse_qkv && gn_fold;
             View n;
@@ -1033,7 +1053,7 @@ struct rs_engine {
             static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 3; }();   // bit 0: fp16, bit 1: split storage
             static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 16384; }();   // (8192 tokens: 32 us fused vs 14 + 15 us apart)
             const int Mtok = X.B * X.H * X.W;
-            const bool fuse_mlp = mlp_fused && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
+            const bool fuse_mlp = mlp_fused && !big_mlp && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
                                   s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.w_for(X.dt) && s.fc2.w_for(X.dt);
             const bool fold2 = fuse_mlp && gn_fold && !ex.dbg && (X.H * X.W) % 128 == 0;
             View n2;
@@ -1433,7 +1453,7 @@ struct rs_engine {
         if (d.used_split && !(cfg.enable_split && split_ok))
             return fail(!cfg.enable_split ? "split precision requested but the engine was created without enable_split"
                                           : "split precision is not available for these weights: " +
-                                                (split_err.empty() ? std::string("a conv / linear weight with |w| >= 30 or a non-finite value (the packing rank has its name)") : split_err));
+                                                (split_err.empty() ? std::string("a non-finite or out-of-fp16-range conv / linear weight (the packing rank has its name)") : split_err));
         // behind the scratch arena: the GroupNorm coefficient pool and the tails' tickets (gn_tail.h), sized by the dry pass
         const size_t scratch_end = (arena.peak + 255) & ~(size_t)255;
         const size_t pool_bytes = (d.pool_peak + 255) & ~(size_t)255, ticket_bytes = d.ticket_used * sizeof(unsigned);
@@ -1603,6 +1623,8 @@ int rs_weights_ready(rs_engine* e) {
     if (getenv("RS_FAKE_DEVICE")) { e->split_ok = true; e->ready = true; return 0; }   // (plumbing check without a GPU, see run())
     if (hipMemcpy(&flags, e->blob.base, sizeof flags, hipMemcpyDeviceToHost) != hipSuccess) return fail("rs_weights_ready: cannot read the blob header");
     e->split_ok = (flags & 1u) != 0;
+    if (e->conv_count > 0 && e->big_w_dev &&
+        hipMemcpy(e->big_w.data(), e->big_w_dev, (size_t)e->conv_count, hipMemcpyDeviceToHost) != hipSuccess) return fail("rs_weights_ready: cannot read the per-layer flags");
     for (auto& kv : e->film_cache) (void)hipFree(kv.second);
     e->film_cache.clear();
     e->ready = true;

@@ -11,11 +11,10 @@
 //
 // Inter-workgroup visibility follows /opt/skills/guides/cdna_hip_programming.md §6 Guideline 16, recipe R1 (the per-XCD L2s are not
 // coherent with each other and a CU's L1 is never refreshed by other CUs' stores):
-//   producer : payload = 8-byte WRITE-THROUGH stores (relaxed agent-scope __hip_atomic_store -> `global_store_dwordx2 ... sc1`), every
-//              storing wave drains them (`s_waitcnt vmcnt(0)`), __syncthreads(), ONE lane draws the ticket with a relaxed agent-scope
-//              fetch_add;
-//   consumer : (the last arriver) the SAME lane issues ONE agent-scope acquire fence behind the ticket, __syncthreads(), then every
-//              wave reads the partials - with sc1 loads on top of the acquire (both forms are valid on their own for sc1 payloads).
+//   producer : payload = 8-byte WRITE-THROUGH stores (relaxed agent-scope __hip_atomic_store -> `global_store_dwordx2 ... sc1`) by ONE
+//              wave, which drains them (`s_waitcnt vmcnt(0)`) before its lane 0 draws the ticket with a relaxed agent-scope fetch_add;
+//   consumer : (the last arriver) the SAME lane issues ONE agent-scope acquire fence behind the ticket, then the same wave reads the
+//              partials - with sc1 loads on top of the acquire (both forms are valid on their own for sc1 payloads).
 // Tickets live in a pool that the engine zeroes with ONE hipMemsetAsync at the start of every call (never reset in-kernel: a poisoned
 // word from an aborted launch cannot survive into the next call); every tail of a call owns its own B words of the pool.
 #pragma once
@@ -50,36 +49,40 @@ __device__ __forceinline__ float2 rs_get_pair(const float* src) {
     return float2{__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32))};
 }
 
-// Called by EVERY thread of a contributing workgroup once its partial sums of image `img` have been stored with rs_pub_pair.  `flag`:
-// one LDS word nobody else uses at that moment.  True in exactly one workgroup per image: the one that arrived last.
-__device__ __forceinline__ bool rs_gn_tail_arrive(const GNTail& t, int img, unsigned* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
+// Called by ONE wave of a contributing workgroup (all 64 lanes, the same wave that stored ALL of the workgroup's partial sums of image
+// `img` with rs_pub_pair) - the other waves of the workgroup never wait: the drain covers only this wave's few write-through stores, and
+// their round trip to memory (1 - 3 us under load) hides behind the other waves' output stores.  A workgroup-wide version (every wave
+// draining, two barriers) cost the halo kernel 5.7 us per launch and the generic split kernel 12 us (its short-lived workgroups run 4 - 8
+// rounds per launch) - more than the coefficient launch it removes (profiles/r4_gn_tail_ab.txt).  True (wave-uniform) in exactly one
+// workgroup per image: the one that arrived last.
+__device__ __forceinline__ bool rs_gn_tail_arrive(const GNTail& t, int img) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have reached memory
+    unsigned last = 0u;
+    if ((threadIdx.x & 63) == 0) {
         const unsigned old = __hip_atomic_fetch_add(t.ticket + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old + 1u == (unsigned)t.expected;
+        last = old + 1u == (unsigned)t.expected ? 1u : 0u;
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *flag = last ? 1u : 0u;
     }
-    __syncthreads();
-    return *flag != 0u;
+    return __builtin_amdgcn_readfirstlane((int)last) != 0;
 }
 
-// The last arriver's work: partials -> per-channel totals -> group statistics -> coefficients.  `lds`: 2 * C + 2 * groups floats of LDS
-// that are free now (called at the very end of the producing kernel).  NT = threads of the workgroup.
-template <int NT>
+// The last arriver's work, by the SAME single wave: partials -> per-channel totals -> group statistics -> coefficients.  `lds`: 2 * C + 2 *
+// groups floats of LDS that no other wave touches.  One wave's LDS operations execute in order: between a phase's writes and the next
+// phase's reads of other lanes' data a drained LDS counter is all the synchronisation there is.  Summation orders are those of
+// gn_apply_kernel's coefficient mode (they do not depend on which lane adds what).
+#define RS_TAIL_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 __device__ __forceinline__ void rs_gn_tail_finish(const GNTail& t, int img, float* lds) {
-    const int tid = threadIdx.x, C = t.C, cpg = C / t.groups;
-    float* chs = lds;                 // [C][2] per-channel totals, later scale row | shift row
+    const int lane = threadIdx.x & 63, C = t.C, cpg = C / t.groups;
+    float* chs = lds;                 // [C][2] per-channel totals (group-partial mode: [slices][groups][2])
     float* gm = lds + 2 * C;          // [groups] mean
     float* gr = gm + t.groups;        // [groups] 1 / sqrt(var + eps)
     const float n = (float)cpg * (float)t.HW;
     if (t.stg) {
         // per-group partials of a statistics pass: the reduction tree of gn_apply_kernel (256 / groups slices, then a fixed-order sum)
         const int nsl = 256 / t.groups;
-        float* ps = chs;              // [nsl][groups][2]
-        if (tid < nsl * t.groups) {
-            const int g = tid % t.groups, sl = tid / t.groups;
+        float* ps = chs;
+        for (int item = lane; item < nsl * t.groups; item += 64) {
+            const int g = item % t.groups, sl = item / t.groups;
             float a = 0.f, q = 0.f;
             for (int s = sl; s < t.Sg; s += nsl) {
                 const float2 v = rs_get_pair(t.stg + (((long long)img * t.Sg + s) * t.groups + g) * 2);
@@ -87,14 +90,14 @@ __device__ __forceinline__ void rs_gn_tail_finish(const GNTail& t, int img, floa
             }
             ps[(sl * t.groups + g) * 2] = a; ps[(sl * t.groups + g) * 2 + 1] = q;
         }
-        __syncthreads();
-        if (tid < t.groups) {
+        RS_TAIL_WAVE_SYNC();
+        for (int g = lane; g < t.groups; g += 64) {
             float a = 0.f, q = 0.f;
-            for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * t.groups + tid) * 2]; q += ps[(sl * t.groups + tid) * 2 + 1]; }
-            rs_gn_group(a, q, n, t.eps, gm[tid], gr[tid]);
+            for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * t.groups + g) * 2]; q += ps[(sl * t.groups + g) * 2 + 1]; }
+            rs_gn_group(a, q, n, t.eps, gm[g], gr[g]);
         }
     } else {
-        for (int c = tid; c < C; c += NT) {
+        for (int c = lane; c < C; c += 64) {
             const bool s0 = c < t.n0;
             const float* in = s0 ? t.st0 + (((long long)img * t.S0) * t.ld0 + c) * 2 : t.st1 + (((long long)img * t.S1) * t.ld1 + (c - t.n0)) * 2;
             const int S = s0 ? t.S0 : t.S1;
@@ -103,15 +106,15 @@ __device__ __forceinline__ void rs_gn_tail_finish(const GNTail& t, int img, floa
             for (int s = 0; s < S; ++s) { const float2 v = rs_get_pair(in + s * step); a += v.x; q += v.y; }
             chs[2 * c] = a; chs[2 * c + 1] = q;
         }
-        __syncthreads();
-        if (tid < t.groups) {
+        RS_TAIL_WAVE_SYNC();
+        for (int g = lane; g < t.groups; g += 64) {
             float a = 0.f, q = 0.f;
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[2 * c]; q += chs[2 * c + 1]; }
-            rs_gn_group(a, q, n, t.eps, gm[tid], gr[tid]);
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[2 * c]; q += chs[2 * c + 1]; }
+            rs_gn_group(a, q, n, t.eps, gm[g], gr[g]);
         }
     }
-    __syncthreads();
-    for (int c = tid; c < C; c += NT) {
+    RS_TAIL_WAVE_SYNC();
+    for (int c = lane; c < C; c += 64) {
         const int g = c / cpg;
         float a, b;
         rs_gn_channel(t.gamma[c], t.beta[c], gm[g], gr[g], t.film, c, C, a, b);

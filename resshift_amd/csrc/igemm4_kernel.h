@@ -507,28 +507,31 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     float* const sb = (float*)(smem + NWV * 64 * ROWB);
     // wave-level sum of one (channel fragment, register) column over the 16 pixel lanes -> LDS
     auto stats_put = [&](int i, int r, float a, float q) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        a = rs_sum16(a); q = rs_sum16(q);   // (DPP adds; same operands and bits as the xor-shuffle butterfly they replace)
         if (lr == 0) { sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
     };
-    auto stats_out = [&]() {   // the four pixel-waves' partials -> one pair per channel of the tile -> global
+    // GroupNorm tail (gn_tail.h): with IGemmParams::tail the workgroup that publishes the LAST statistics of image b also writes the
+    // consuming GroupNorm's coefficients.  All of it is wave 0's business: it alone gathers and stores the tile's statistics, drains those
+    // few stores and draws the ticket while the other seven waves are already staging and storing the output tile (nobody waits for the
+    // write-through round trip), and - in the image's last workgroup - it computes the coefficients at the very end, in LDS nobody else uses.
+    bool tail_last = false;
+    float* const tail_lds = (float*)(smem + NWV * 64 * ROWB + NWV * (BC / 2) * 2 * sizeof(float));
+    auto stats_out = [&]() {   // the pixel-waves' partials -> one pair per channel of the tile -> global
         __syncthreads();
-        if (tid < BC && n0 + tid < p.Cout) {
-            const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
+        if (wave != 0) return;
+        for (int c = lane; c < BC; c += 64) {
+            if (n0 + c >= p.Cout) break;
+            const int hw_ = c / (BC / 2), cl = c - hw_ * (BC / 2);   // channel-wave, channel inside its half
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < WPX; ++w4) { a += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPX + w4) * (BC / 2) + cl) * 2 + 1]; }
             // (SEG = 16: the tile IS the image; SEG = 8 never produces statistics here - four images per tile)
-            float* dst = ystats + ((SEG ? (long long)b : (long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + tid) * 2;
+            float* dst = ystats + ((SEG ? (long long)b : (long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + c) * 2;
             if (tail_on) rs_pub_pair(dst, a, q);   // write-through: another workgroup (the image's last arriver) reads it inside this launch
             else { dst[0] = a; dst[1] = q; }
         }
+        if (tail_on) tail_last = rs_gn_tail_arrive(p.tail, b);
     };
-    // GroupNorm tail (gn_tail.h): with IGemmParams::tail the workgroup that publishes the LAST statistics of image b also writes the
-    // consuming GroupNorm's coefficients - the ticket is drawn right behind the statistics (the drain covers only those few stores), the
-    // coefficient work waits until this workgroup's own output tile is on its way
-    unsigned* const tail_flag = (unsigned*)(smem + NWV * 64 * ROWB + NWV * (BC / 2) * 2 * sizeof(float));
-    bool tail_last = false;
     if constexpr (SPLIT) {
         // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
@@ -566,7 +569,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             }
         }
         if (ystats) stats_out();
-        if (ystats && tail_on) tail_last = rs_gn_tail_arrive(p.tail, b, tail_flag);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -664,7 +666,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
         };
         if (res_ok) run(std::true_type{}); else run(std::false_type{});
         if (ystats) stats_out();
-        if (ystats && tail_on) tail_last = rs_gn_tail_arrive(p.tail, b, tail_flag);
         RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
         for (int idx = lane; idx < NITEM; idx += 64) {
             const int row = idx / CPR, c8 = idx - row * CPR;
@@ -673,10 +674,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
     }
-    if (tail_last) {   // (workgroup-uniform) every wave is done with its staging tile behind this barrier: the LDS is free
-        __syncthreads();
-        rs_gn_tail_finish<NT>(p.tail, b, (float*)smem);
-    }
+    if (tail_last) rs_gn_tail_finish(p.tail, b, tail_lds);   // (wave 0 of the image's last workgroup only)
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 3] = clock64();
 #endif

@@ -410,7 +410,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
         if (p.ystats) {
             constexpr int WT = (BP / WPN) * ((BC / 2) * 2 + 16);
             float* const sb = (float*)(smem + NWV * 2 * WT);         // behind the staging tiles: [NWV][BC / 2][2]
-            unsigned* const tflag = (unsigned*)(sb + NWV * (BC / 2) * 2);
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
@@ -418,23 +417,25 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
                     float a = 0.f, q = 0.f;
 #pragma unroll
                     for (int j = 0; j < FP; ++j) { a += am[i][j][r]; q = fmaf(am[i][j][r], am[i][j][r], q); }
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                    a = rs_sum16(a); q = rs_sum16(q);
                     if (lr == 0) { sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (BC / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
                 }
             __syncthreads();
             const int hw = p.Ho * p.Wo;
             tail_img = m0 / hw;
-            if (tid < BC && n0 + tid < p.Cout) {
-                const int hw_ = tid / (BC / 2), cl = tid - hw_ * (BC / 2);   // channel-wave, channel inside its half
-                float a = 0.f, q = 0.f;
+            if (wave == 0) {   // (the other waves go on to stage and store the tile; the tail's round trip to memory is wave 0's alone: gn_tail.h)
+                for (int c = lane; c < BC; c += 64) {
+                    if (n0 + c >= p.Cout) break;
+                    const int hw_ = c / (BC / 2), cl = c - hw_ * (BC / 2);   // channel-wave, channel inside its half
+                    float a = 0.f, q = 0.f;
 #pragma unroll
-                for (int w4 = 0; w4 < WPN; ++w4) { a += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2 + 1]; }
-                float* dst = p.ystats + (((long long)tail_img * (hw / BP) + (m0 - tail_img * hw) / BP) * p.ystats_ld + n0 + tid) * 2;
-                if (p.tail.coef) rs_pub_pair(dst, a, q);
-                else { dst[0] = a; dst[1] = q; }
+                    for (int w4 = 0; w4 < WPN; ++w4) { a += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2 + 1]; }
+                    float* dst = p.ystats + (((long long)tail_img * (hw / BP) + (m0 - tail_img * hw) / BP) * p.ystats_ld + n0 + c) * 2;
+                    if (p.tail.coef) rs_pub_pair(dst, a, q);
+                    else { dst[0] = a; dst[1] = q; }
+                }
+                if (p.tail.coef) tail_last = rs_gn_tail_arrive(p.tail, tail_img);
             }
-            if (p.tail.coef) tail_last = rs_gn_tail_arrive(p.tail, tail_img, tflag);
         }
         f16* y = (f16*)p.y + 2 * z * p.bs_y;
         // wave tile (BP/WPN rows x BC/2 channels) staged twice (hi, lo) with a padded row pitch, then 16-byte stores
@@ -489,9 +490,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             }
         }
     }
-    if (tail_last) {   // (workgroup-uniform) every wave is done with its staging tile behind this barrier: the LDS is free
-        __syncthreads();
-        rs_gn_tail_finish<64 * NWV>(p.tail, tail_img, (float*)smem);
+    if (tail_last) {   // (wave 0 of the image's last workgroup only; scratch behind the staging tiles and the statistics partials)
+        constexpr int WT2 = (BP / WPN) * ((BC / 2) * 2 + 16);
+        rs_gn_tail_finish(p.tail, tail_img, (float*)(smem + NWV * 2 * WT2 + NWV * (BC / 2) * 2 * sizeof(float)));
     }
     RS_IGS_STAMP(3);
 }

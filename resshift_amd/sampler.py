@@ -62,15 +62,30 @@ def reload_model(model: torch.nn.Module, ckpt: Mapping[str, torch.Tensor]) -> No
 
 
 class BaseSampler:
+    # precision policies by name: (UNet, encoder, decoder) storage types
+    POLICIES = {"parity": ("split", "split", "fp16"), "fp16": ("fp16", "fp16", "fp16"), "fp32": ("fp32", "fp32", "fp32"),
+                "split": ("split", "split", "split")}
+
     def __init__(self, configs, sf=4, use_amp=True, chop_size=128, chop_stride=128, chop_bs=1, padding_offset=16, seed=10000,
-                 state_dicts: Optional[Mapping[str, Mapping[str, torch.Tensor]]] = None, blob_cache=None):
+                 state_dicts: Optional[Mapping[str, Mapping[str, torch.Tensor]]] = None, blob_cache=None, precision=None, pack="policy"):
         """`state_dicts` ({"model": sd, "autoencoder": sd}) replaces checkpoint files, e.g. for synthetic-weight runs.
-        `blob_cache`: file that keeps the packed device weights between runs (sharding.build_engine_with_broadcast)."""
+        `blob_cache`: file that keeps the packed device weights between runs (sharding.build_engine_with_broadcast).
+        `precision`: "parity" | "fp16" | "fp32" | "split" (POLICIES).  Default: "parity" when `use_amp` (the reduced-precision path of the
+        reference, sampler.py:185 - here the fastest policy that still reproduces the reference's CPU output to >= 60 dB: split-precision
+        encoder + UNet, fp16 decoder; the reference's own autocast path, and "fp16" here, flip 2 - 7 % of the VQ codes), "fp32" otherwise.
+        `pack`: "policy" - the engine packs, broadcasts and caches only the weight forms that policy needs (a later set_precision to a
+        form that was not packed fails loudly); "all" - every form (a process that switches policies)."""
         self.configs = configs if isinstance(configs, Mapping) else load_config(configs)
         self.sf = sf
         self.chop_size, self.chop_stride, self.chop_bs = chop_size, chop_stride, chop_bs
         self.seed = seed
         self.use_amp = use_amp
+        self.precision = precision if precision is not None else ("parity" if use_amp else "fp32")
+        if self.precision not in self.POLICIES:
+            raise ValueError(f"unknown precision policy {self.precision!r} (one of {sorted(self.POLICIES)})")
+        if pack not in ("policy", "all"):
+            raise ValueError("pack must be 'policy' or 'all'")
+        self.pack = pack
         self.padding_offset = padding_offset
         self._state_dicts = state_dicts
         self._blob_cache = blob_cache
@@ -115,13 +130,13 @@ class BaseSampler:
             model, autoencoder,
             load_fn=lambda: (self._load_sd("model", c["model"].get("ckpt_path")), self._load_sd("autoencoder", c["autoencoder"].get("ckpt_path"))),
             rank=self.rank, world=self.num_gpus, blob_cache=self._blob_cache,
-            cache_fingerprint=sharding.checkpoint_fingerprint([c["model"].get("ckpt_path"), c["autoencoder"].get("ckpt_path")]))
+            cache_fingerprint=sharding.checkpoint_fingerprint([c["model"].get("ckpt_path"), c["autoencoder"].get("ckpt_path")]),
+            precisions=None if self.pack == "all" else set(self.POLICIES[self.precision]))
         self.base_diffusion.adopt_engine(model, autoencoder, eng)
         self.model = model.eval()
         self.autoencoder = autoencoder.eval()
         self.engine = eng
-        # use_amp=True is the reference's fp16 autocast path (sampler.py:185); False runs the exact fp32 kernels
-        self.base_diffusion.set_precision(*( ["fp16"] * 3 if self.use_amp else ["fp32"] * 3 ))
+        self.base_diffusion.set_precision(*self.POLICIES[self.precision])
 
     def set_precision(self, unet=None, encode=None, decode=None):
         self.base_diffusion.set_precision(unet, encode, decode)

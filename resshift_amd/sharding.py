@@ -193,8 +193,21 @@ def _blob_cache_save(path, eng, fingerprint: bytes = b"\0" * 16) -> None:
     os.replace(tmp, path)
 
 
+def weight_forms(precisions) -> dict:
+    """Engine(enable_f16 / enable_f32 / enable_split) flags for the storage types a run will ask for.  `precisions`: None (all three
+    forms: a process that switches policies at will, e.g. the test-suite) or an iterable of precision names ("fp16", "fp32", "split" and
+    their aliases) - the engine then packs, broadcasts and caches only those forms of every conv / linear weight (a parity-policy
+    run: split for the encoder + UNet, fp16 for the decoder - no fp32 copy), and a later call that names another precision fails loudly."""
+    if precisions is None:
+        return dict(enable_f16=True, enable_f32=True, enable_split=True)
+    from .engine import F16, F32, SPLIT, parse_precision
+
+    want = {parse_precision(p) for p in precisions}
+    return dict(enable_f16=F16 in want, enable_f32=F32 in want, enable_split=SPLIT in want)
+
+
 def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequence], rank: int, world: int, blob_cache=None,
-                                cache_fingerprint: bytes = b"\0" * 16):
+                                cache_fingerprint: bytes = b"\0" * 16, precisions=None):
     """Create the fused UNet+AE engine on this rank's GPU.  Rank 0 calls `load_fn()` -> (unet_sd, ae_sd), fills the
     drop-in modules (reload_model semantics) and packs the device blob; the blob is then broadcast.
 
@@ -206,7 +219,7 @@ def build_engine_with_broadcast(model, autoencoder, load_fn: Callable[[], Sequen
     from .sampler import reload_model
 
     dev = next(model.parameters()).device
-    eng = Engine(unet_params=model.params, ae_params=autoencoder.params, device=dev)
+    eng = Engine(unet_params=model.params, ae_params=autoencoder.params, device=dev, **weight_forms(precisions))   # (`precisions`: weight_forms)
     if rank == 0 and not _blob_cache_load(blob_cache, eng, cache_fingerprint):
         unet_sd, ae_sd = load_fn()
         with torch.no_grad():

