@@ -119,7 +119,7 @@ def per_kernel_rooflines(eng):
     arithmetic they run (split storage: three fp16 MFMAs per product -> 2500 / 3)"""
     fam_peak = [MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"],
                 MFMA_PEAK_TFLOPS["fp32"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["split"],
-                MFMA_PEAK_TFLOPS["fp16"]]
+                MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"]]
     return [{"kernel": name, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
              "frac": round(fl / (ms * 1e-3) / 1e12 / pk, 4), "ms_per_step": round(ms, 2), "launches_per_step": n}
             for (name, fl, ms, n), pk in zip(eng.profile_families(), fam_peak) if n and ms > 0]

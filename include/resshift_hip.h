@@ -217,6 +217,9 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
  * [nz][T][C], vt [nz][C][T] (v transposed, without its bias), bv_dev [C] fp32 (v bias, may be null), o [nz][T][C] =
  * softmax(q k^T / sqrt(C)) v + bv; C in {128, 256, 512}, T a multiple of 128 (ae_attn.hip) */
 int rs_op_ae_flash_attention(const void* q, const void* k, const void* vt, const float* bv_dev, void* o, int nz, int T, int C, void* stream);
+/* the same on split storage (RS_PREC_SPLIT tensors of (hi, lo) fp16 pairs: q, k, o records [C hi | C lo] per token, vt rows [T hi | T lo] per
+ * channel); C = 512, T a multiple of 64 (ae_attn_split.hip; the reference's memory-efficient AttnBlock is model.py:205-268) */
+int rs_op_ae_flash_attention_split(const void* q, const void* k, const void* vt, const float* bv_dev, void* o, int nz, int T, int C, void* stream);
 /* fused Swin MLP, fp16 device tensors: y[M][E] = res + fc2(GELU(fc1(x))) with fc1 weights [HD][E], fc2 weights [E][HD]
  * (row-major fp16, device), fp32 biases; res may be null (models/swin_transformer.py:17-33,279) */
 int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,

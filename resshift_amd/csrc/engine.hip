@@ -52,6 +52,9 @@ int rs_win_attn_qkv_split_launch(const WinAttnParams* p, hipStream_t st);
 int rs_ae_flash_supported(int C, int T);
 int rs_ae_flash_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C,
                        float scale, hipStream_t st);
+int rs_ae_flash_split_supported(int C, int T);
+int rs_ae_flash_split_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C,
+                             float scale, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                              int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, hipStream_t st);
@@ -246,7 +249,7 @@ struct Exec {
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     // per kernel family of the MFMA path (rs_profile_families): algorithmic FLOPs, launches, and the family of every bracket
-    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_AEFLASH, F_COUNT };
+    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_AEFLASH, F_AEFLASH_S, F_COUNT };
     double fam_flops[F_COUNT] = {};
     long long fam_launches[F_COUNT] = {};
     std::vector<unsigned char> fam_of;   // family of bracket k (profiling pass only)
@@ -317,15 +320,18 @@ struct Exec {
         if (e1) (void)hipEventRecord(e1, st);
     }
     // streaming AE attention (ae_attn.hip): QK^T and PV of nz images, q / k / v^T read once, o written once
-    void ae_flash(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C, float scale) {
+    void ae_flash(const void* q, int ldq, const void* k, int ldk, const void* vt, const float* bv, void* o, int ldo, int nz, int T, int C, float scale,
+                  int dt = RS_F16) {
+        const int sp = dt == RS_F16S;
         const double fl = 4.0 * (double)nz * (double)T * (double)T * (double)C;
-        igemm_flops[0] += fl;
-        fam_note(F_AEFLASH, fl, T, T, C, nz);
-        igemm_bytes += 2.0 * 4.0 * (double)nz * T * C;
+        igemm_flops[sp ? 2 : 0] += fl;
+        fam_note(sp ? F_AEFLASH_S : F_AEFLASH, fl, T, T, C, nz);
+        igemm_bytes += (sp ? 4.0 : 2.0) * 4.0 * (double)nz * T * C;
         ++igemm_launches;
         hipEvent_t e0, e1;
         bracket(prof, st, e0, e1);
-        check(rs_ae_flash_launch(q, ldq, k, ldk, vt, bv, o, ldo, nz, T, C, scale, st), "ae_flash_attn");
+        if (sp) check(rs_ae_flash_split_launch(q, ldq, k, ldk, vt, bv, o, ldo, nz, T, C, scale, st), "ae_flash_attn_split");
+        else check(rs_ae_flash_launch(q, ldq, k, ldk, vt, bv, o, ldo, nz, T, C, scale, st), "ae_flash_attn");
         if (e1) (void)hipEventRecord(e1, st);
     }
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
@@ -1098,12 +1104,15 @@ struct rs_engine {
         // fp16 storage: streaming attention (ae_attn.hip) - S never reaches HBM; RS_AE_FLASH=0 keeps the row-block path below (A/B runs),
         // which also serves fp32 / split storage and token counts that are not multiples of 128
         static const bool flash_on = []() { const char* e = getenv("RS_AE_FLASH"); return !(e && e[0] == '0'); }();
-        if (flash_on && dt == RS_F16 && rs_ae_flash_supported(C, T) && a.v.wh) {
-            char* vTa = (char*)ex.raw((size_t)X.B * C * T * 2);
+        // split storage (the encoder of the parity policy): the same on (hi, lo) pairs, ae_attn_split.hip (round 4)
+        const bool flash16 = dt == RS_F16 && rs_ae_flash_supported(C, T) && a.v.wh;
+        const bool flash_s = dt == RS_F16S && rs_ae_flash_split_supported(C, T) && a.v.ws;
+        if (flash_on && (flash16 || flash_s)) {
+            char* vTa = (char*)ex.raw((size_t)X.B * C * T * rs_dtype_size(dt));
             if (!ex.dry) {
                 // vT[z][c][t] = sum_k Wv[c][k] n[z][t][k]   (bias added to the attention output: softmax rows sum to 1)
-                gemm_nt(ex, a.v.wh, 0, n.p, (long long)T * C, nullptr, vTa, (long long)C * T, X.B, C, T, C, 1.f, dt, dt);
-                ex.ae_flash(q.p, q.ld, k.p, k.ld, vTa, a.v.bias, o.p, o.ld, X.B, T, C, 1.0f / std::sqrt((float)C));
+                gemm_nt(ex, a.v.w_for(dt), 0, n.p, (long long)T * C, nullptr, vTa, (long long)C * T, X.B, C, T, C, 1.f, dt, dt);
+                ex.ae_flash(q.p, q.ld, k.p, k.ld, vTa, a.v.bias, o.p, o.ld, X.B, T, C, 1.0f / std::sqrt((float)C), dt);
             }
             want_stats(ex, a.proj, o, Y, &X, 1, 0, 1);
             conv1(ex, a.proj, o, Y, &X);
@@ -2088,6 +2097,12 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
 int rs_op_ae_flash_attention(const void* q, const void* k, const void* vt, const float* bv_dev, void* o, int nz, int T, int C, void* stream) {
     const int rc = rs_ae_flash_launch(q, C, k, C, vt, bv_dev, o, C, nz, T, C, 1.0f / std::sqrt((float)C), (hipStream_t)stream);
     if (rc) fail("streaming AE attention launch rejected the shape (fp16, C in {128, 256, 512}, T a multiple of 128)");
+    return rc;
+}
+
+int rs_op_ae_flash_attention_split(const void* q, const void* k, const void* vt, const float* bv_dev, void* o, int nz, int T, int C, void* stream) {
+    const int rc = rs_ae_flash_split_launch(q, C, k, C, vt, bv_dev, o, C, nz, T, C, 1.0f / std::sqrt((float)C), (hipStream_t)stream);
+    if (rc) fail("split-storage streaming AE attention launch rejected the shape (C = 512, T a multiple of 64)");
     return rc;
 }
 

@@ -49,72 +49,81 @@ __device__ __forceinline__ float2 rs_get_pair(const float* src) {
     return float2{__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32))};
 }
 
-// Called by ONE wave of a contributing workgroup (all 64 lanes, the same wave that stored ALL of the workgroup's partial sums of image
-// `img` with rs_pub_pair) - the other waves of the workgroup never wait: the drain covers only this wave's few write-through stores, and
-// their round trip to memory (1 - 3 us under load) hides behind the other waves' output stores.  A workgroup-wide version (every wave
-// draining, two barriers) cost the halo kernel 5.7 us per launch and the generic split kernel 12 us (its short-lived workgroups run 4 - 8
-// rounds per launch) - more than the coefficient launch it removes (profiles/r4_gn_tail_ab.txt).  True (wave-uniform) in exactly one
-// workgroup per image: the one that arrived last.
+// ARRIVE - by ONE wave of a contributing workgroup (all 64 lanes; the wave that stored ALL of the workgroup's partial sums of image `img`
+// with rs_pub_pair): the other waves never wait for the write-through round trip (1 - 3 us under load), it hides behind their output
+// stores.  Returns (wave-uniform) whether this workgroup drew the image's last ticket; the caller parks that in an LDS word for FINISH.
 __device__ __forceinline__ bool rs_gn_tail_arrive(const GNTail& t, int img) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have reached memory
     unsigned last = 0u;
     if ((threadIdx.x & 63) == 0) {
         const unsigned old = __hip_atomic_fetch_add(t.ticket + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = old + 1u == (unsigned)t.expected ? 1u : 0u;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (covers the CU's L1: every wave of the workgroup, behind a barrier)
     }
     return __builtin_amdgcn_readfirstlane((int)last) != 0;
 }
 
-// The last arriver's work, by the SAME single wave: partials -> per-channel totals -> group statistics -> coefficients.  `lds`: 2 * C + 2 *
-// groups floats of LDS that no other wave touches.  One wave's LDS operations execute in order: between a phase's writes and the next
-// phase's reads of other lanes' data a drained LDS counter is all the synchronisation there is.  Summation orders are those of
-// gn_apply_kernel's coefficient mode (they do not depend on which lane adds what).
-#define RS_TAIL_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// FINISH - by ALL NT threads of the image's last workgroup, behind a workgroup barrier at the very end of the producing kernel (the LDS is
+// free: `lds` needs 2 * C + 2 * groups floats): partials -> per-channel totals -> group statistics -> coefficients.  One thread per channel,
+// its S partials requested in batches of 16 before the first is added (a loop that waits for each load in turn is S dependent round trips
+// to memory at the tail of the launch - measured: it cost more than the coefficient launch the tail replaces); the additions keep the
+// order s = 0, 1, ... of gn_apply_kernel's coefficient mode, so the two paths agree bit for bit (a padded slot adds +0.0f).
+template <int NT>
 __device__ __forceinline__ void rs_gn_tail_finish(const GNTail& t, int img, float* lds) {
-    const int lane = threadIdx.x & 63, C = t.C, cpg = C / t.groups;
+    const int tid = threadIdx.x, C = t.C, cpg = C / t.groups;
     float* chs = lds;                 // [C][2] per-channel totals (group-partial mode: [slices][groups][2])
     float* gm = lds + 2 * C;          // [groups] mean
     float* gr = gm + t.groups;        // [groups] 1 / sqrt(var + eps)
     const float n = (float)cpg * (float)t.HW;
+    constexpr int NB = 16;
     if (t.stg) {
         // per-group partials of a statistics pass: the reduction tree of gn_apply_kernel (256 / groups slices, then a fixed-order sum)
         const int nsl = 256 / t.groups;
         float* ps = chs;
-        for (int item = lane; item < nsl * t.groups; item += 64) {
+        for (int item = tid; item < nsl * t.groups; item += NT) {
             const int g = item % t.groups, sl = item / t.groups;
+            const float* in = t.stg + (((long long)img * t.Sg) * t.groups + g) * 2;
             float a = 0.f, q = 0.f;
-            for (int s = sl; s < t.Sg; s += nsl) {
-                const float2 v = rs_get_pair(t.stg + (((long long)img * t.Sg + s) * t.groups + g) * 2);
-                a += v.x; q += v.y;
+            for (int s0 = sl; s0 < t.Sg; s0 += NB * nsl) {
+                float2 v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { const int s = s0 + u * nsl; v[u] = s < t.Sg ? rs_get_pair(in + (long long)s * t.groups * 2) : float2{0.f, 0.f}; }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { a += v[u].x; q += v[u].y; }
             }
             ps[(sl * t.groups + g) * 2] = a; ps[(sl * t.groups + g) * 2 + 1] = q;
         }
-        RS_TAIL_WAVE_SYNC();
-        for (int g = lane; g < t.groups; g += 64) {
+        __syncthreads();
+        if (tid < t.groups) {
             float a = 0.f, q = 0.f;
-            for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * t.groups + g) * 2]; q += ps[(sl * t.groups + g) * 2 + 1]; }
-            rs_gn_group(a, q, n, t.eps, gm[g], gr[g]);
+            for (int sl = 0; sl < nsl; ++sl) { a += ps[(sl * t.groups + tid) * 2]; q += ps[(sl * t.groups + tid) * 2 + 1]; }
+            rs_gn_group(a, q, n, t.eps, gm[tid], gr[tid]);
         }
     } else {
-        for (int c = lane; c < C; c += 64) {
-            const bool s0 = c < t.n0;
-            const float* in = s0 ? t.st0 + (((long long)img * t.S0) * t.ld0 + c) * 2 : t.st1 + (((long long)img * t.S1) * t.ld1 + (c - t.n0)) * 2;
-            const int S = s0 ? t.S0 : t.S1;
-            const long long step = 2ll * (s0 ? t.ld0 : t.ld1);
+        for (int c = tid; c < C; c += NT) {
+            const bool s0_ = c < t.n0;
+            const float* in = s0_ ? t.st0 + (((long long)img * t.S0) * t.ld0 + c) * 2 : t.st1 + (((long long)img * t.S1) * t.ld1 + (c - t.n0)) * 2;
+            const int S = s0_ ? t.S0 : t.S1;
+            const long long step = 2ll * (s0_ ? t.ld0 : t.ld1);
             float a = 0.f, q = 0.f;
-            for (int s = 0; s < S; ++s) { const float2 v = rs_get_pair(in + s * step); a += v.x; q += v.y; }
+            for (int s0 = 0; s0 < S; s0 += NB) {
+                float2 v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) v[u] = s0 + u < S ? rs_get_pair(in + (s0 + u) * step) : float2{0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { a += v[u].x; q += v[u].y; }
+            }
             chs[2 * c] = a; chs[2 * c + 1] = q;
         }
-        RS_TAIL_WAVE_SYNC();
-        for (int g = lane; g < t.groups; g += 64) {
+        __syncthreads();
+        if (tid < t.groups) {
             float a = 0.f, q = 0.f;
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[2 * c]; q += chs[2 * c + 1]; }
-            rs_gn_group(a, q, n, t.eps, gm[g], gr[g]);
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[2 * c]; q += chs[2 * c + 1]; }
+            rs_gn_group(a, q, n, t.eps, gm[tid], gr[tid]);
         }
     }
-    RS_TAIL_WAVE_SYNC();
-    for (int c = lane; c < C; c += 64) {
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
         const int g = c / cpg;
         float a, b;
         rs_gn_channel(t.gamma[c], t.beta[c], gm[g], gr[g], t.film, c, C, a, b);

@@ -82,8 +82,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IGemmParams p,
         }
     }
     // GroupNorm tail (gn_tail.h): the last (slab, channel block) workgroup of image b writes the consuming GroupNorm's coefficients - wave 0
-    // stored the partials and is the only wave still at work, `lds` is its scratch now
-    if (p.tail.coef && tid < 64 && rs_gn_tail_arrive(p.tail, b)) rs_gn_tail_finish(p.tail, b, lds);
+    // stored the partials and draws the ticket
+    if (p.tail.coef) {
+        unsigned* const flag = (unsigned*)&lds[2 * 1280 + 2 * 32];
+        if (tid < 64) { const bool last = rs_gn_tail_arrive(p.tail, b); if (tid == 0) *flag = last ? 1u : 0u; }
+        __syncthreads();
+        if (*flag) rs_gn_tail_finish<256>(p.tail, b, lds);
+    }
 }
 
 int reduce_stats_launch(const IGemmParams& p_in, int out_dt, hipStream_t st) {

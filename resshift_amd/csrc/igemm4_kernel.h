@@ -513,9 +513,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // GroupNorm tail (gn_tail.h): with IGemmParams::tail the workgroup that publishes the LAST statistics of image b also writes the
     // consuming GroupNorm's coefficients.  All of it is wave 0's business: it alone gathers and stores the tile's statistics, drains those
     // few stores and draws the ticket while the other seven waves are already staging and storing the output tile (nobody waits for the
-    // write-through round trip), and - in the image's last workgroup - it computes the coefficients at the very end, in LDS nobody else uses.
-    bool tail_last = false;
-    float* const tail_lds = (float*)(smem + NWV * 64 * ROWB + NWV * (BC / 2) * 2 * sizeof(float));
+    // write-through round trip); at the very end, behind one barrier, the image's last workgroup computes the coefficients with all its threads.
+    unsigned* const tail_flag = (unsigned*)(smem + NWV * 64 * ROWB + NWV * (BC / 2) * 2 * sizeof(float));   // behind the staging tiles and the partials
     auto stats_out = [&]() {   // the pixel-waves' partials -> one pair per channel of the tile -> global
         __syncthreads();
         if (wave != 0) return;
@@ -530,12 +529,20 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             if (tail_on) rs_pub_pair(dst, a, q);   // write-through: another workgroup (the image's last arriver) reads it inside this launch
             else { dst[0] = a; dst[1] = q; }
         }
-        if (tail_on) tail_last = rs_gn_tail_arrive(p.tail, b);
+        if (tail_on) { const bool last = rs_gn_tail_arrive(p.tail, b); if (lane == 0) *tail_flag = last ? 1u : 0u; }
     };
     if constexpr (SPLIT) {
         // values finished in place (exact fp32 arithmetic), then two staging passes: the hi halves, then the lo halves
         const float osc = p.out_scale * RS_LO_INV;   // the accumulator carries 2^11 x the sum (see the header)
         const int act = p.act, ldres = p.ldres;
+#ifdef RS_IG4_SPLIT_RES_FRAGS   // (A/B builds: the round-3 form everywhere)
+        constexpr bool RES_FRAGS = true;
+#else
+        constexpr bool RES_FRAGS = SEG != 0;   // (the small-plane instantiations have no registers to spare for the row form: 4 - 5 spills; their tiles finish through the split-K reduce kernel anyway)
+#endif
+        if constexpr (RES_FRAGS) {
+        // the residual in accumulator layout, one channel fragment ahead: 8 B per lane = 16 quarter-used cache lines per wave instruction, five
+        // dependent round trips
         __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
         // (split storage: all FC fragment rows at once would need 80 registers next to the 80 accumulators)
         f16x4 rh[2][FP], rl[2][FP];   // residual of channel fragment i + 1 in flight while fragment i is finished
@@ -567,6 +574,75 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                     stats_put(i, r, a, q);
                 }
             }
+        }
+        } else {
+        // The residual as ROWS (16 B per lane, the store loop's addressing: a pixel's BC / 2 channels are contiguous - a quarter of the
+        // cache-line look-ups of the accumulator-layout fetch, as in the fp16 epilogue below), one plane at a time through the wave-private
+        // staging tile: the hi rows are requested in FRONT of the barrier that ends the K loop, the lo rows travel while the hi cells are
+        // added.  v + hi, then + lo 2^-11 by fma: one fp32 rounding more than v + join(hi, lo) (the stored pair reproduces the sum to
+        // 2^-23 either way).
+        uint4 rq[CPR];
+        auto load_rows = [&](int plane) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                const int idx = lane + 64 * k, row = idx / CPR, c8 = idx - row * CPR;
+                const int n = n0 + wc * (BC / 2) + c8 * 8;
+                rq[k] = n < p.Cout ? *(const uint4*)(res + pixel(row) * ldres * 2 + plane * ldres + n) : uint4{0u, 0u, 0u, 0u};
+            }
+        };
+        auto park_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                const int idx = lane + 64 * k, row = idx / CPR, c8 = idx - row * CPR;
+                *(uint4*)(stg + row * ROWB + c8 * 16) = rq[k];
+            }
+            RS_STAGING_SYNC();
+        };
+        if (res_ok) load_rows(0);
+        __syncthreads();  // all waves done with the LDS: the epilogue reuses it as staging space
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                f32x4 v = acc[i][j] * osc + bvs[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { if (act == RS_ACT_SILU) v[r] = rs_silu(v[r]); else if (act == RS_ACT_GELU) v[r] = rs_gelu(v[r]); }
+                acc[i][j] = v;
+            }
+        if (res_ok) {
+            park_rows();
+            load_rows(1);          // the lo rows travel while the hi cells are added
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const f16x4 c = *(const f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)c[r];
+                }
+            RS_STAGING_SYNC();     // every lane of the wave has read its hi cells
+            park_rows();
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const f16x4 c = *(const f16x4*)(stg + (j * 16 + lr) * ROWB + (i * 16 + lg * 4) * 2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf((float)c[r], RS_LO_INV, acc[i][j][r]);
+                }
+            RS_STAGING_SYNC();     // ... and its lo cells: the tile is free for the store passes
+        }
+        if (ystats) {   // (the stored pair reproduces v to 2^-23)
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = 0.f, q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) { a += acc[i][j][r]; q = fmaf(acc[i][j][r], acc[i][j][r], q); }
+                    stats_put(i, r, a, q);
+                }
+        }
         }
         if (ystats) stats_out();
 #pragma unroll
@@ -674,7 +750,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             *(uint4*)(y + pixel(row) * p.ldy + n) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
     }
-    if (tail_last) rs_gn_tail_finish(p.tail, b, tail_lds);   // (wave 0 of the image's last workgroup only)
+    if (tail_on && ystats) {   // (kernel-uniform) every wave is done with its staging tile behind this barrier: the image's last workgroup turns to the coefficients
+        __syncthreads();
+        if (*tail_flag) rs_gn_tail_finish<NT>(p.tail, b, (float*)smem);
+    }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 3] = clock64();
 #endif

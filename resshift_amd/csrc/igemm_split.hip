@@ -434,8 +434,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
                     if (p.tail.coef) rs_pub_pair(dst, a, q);
                     else { dst[0] = a; dst[1] = q; }
                 }
-                if (p.tail.coef) tail_last = rs_gn_tail_arrive(p.tail, tail_img);
+                if (p.tail.coef) { const bool last = rs_gn_tail_arrive(p.tail, tail_img); if (lane == 0) *(unsigned*)(sb + NWV * (BC / 2) * 2) = last ? 1u : 0u; }
             }
+            tail_last = p.tail.coef != nullptr;   // (here: "a tail is attached"; the flag word decides behind the end-of-kernel barrier)
         }
         f16* y = (f16*)p.y + 2 * z * p.bs_y;
         // wave tile (BP/WPN rows x BC/2 channels) staged twice (hi, lo) with a padded row pitch, then 16-byte stores
@@ -490,9 +491,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             }
         }
     }
-    if (tail_last) {   // (wave 0 of the image's last workgroup only; scratch behind the staging tiles and the statistics partials)
+    if (tail_last) {   // (kernel-uniform) every wave is done with its staging tile behind this barrier: the image's last workgroup turns to the coefficients
         constexpr int WT2 = (BP / WPN) * ((BC / 2) * 2 + 16);
-        rs_gn_tail_finish(p.tail, tail_img, (float*)(smem + NWV * 2 * WT2 + NWV * (BC / 2) * 2 * sizeof(float)));
+        __syncthreads();
+        if (*(const unsigned*)(smem + NWV * 2 * WT2 + NWV * (BC / 2) * 2 * sizeof(float))) rs_gn_tail_finish<64 * NWV>(p.tail, tail_img, (float*)smem);
     }
     RS_IGS_STAMP(3);
 }

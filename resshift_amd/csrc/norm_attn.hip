@@ -73,9 +73,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNParams p, GNTail tail) 
         if (tail.coef) rs_pub_pair(out, a, q);
         else { out[0] = a; out[1] = q; }
     }
-    // (wave 0 stored the partials - tid < groups <= 32 - and is the only wave still at work: `red`, 256 x 17 floats, is its scratch now;
-    // the coefficients need 2 C + 2 groups <= 4160 of them)
-    if (tail.coef && tid < 64 && rs_gn_tail_arrive(tail, b)) rs_gn_tail_finish(tail, b, &red[0][0]);
+    // (wave 0 stored the partials - tid < groups <= 32 - and draws the ticket; `red`, 256 x 17 floats, is the last workgroup's scratch)
+    if (tail.coef) {
+        unsigned* const flag = (unsigned*)&red[255][16];   // (behind the coefficient scratch: 2 C + 2 groups <= 4160 floats)
+        if (tid < 64) { const bool last = rs_gn_tail_arrive(tail, b); if (tid == 0) *flag = last ? 1u : 0u; }
+        __syncthreads();
+        if (*flag) rs_gn_tail_finish<256>(tail, b, &red[0][0]);
+    }
 }
 
 // Element pass of the apply kernel.  Thread (pp, j) owns the 8-channel chunk j for good - its 16 affine coefficients

@@ -180,6 +180,21 @@ def ae_flash_attention(q, k, v, bv=None):
     return o
 
 
+def ae_flash_attention_split(q, k, v, bv=None):
+    """q, k, v: [nz, T, C] fp32 device tensors -> softmax(q k^T / sqrt(C)) (v + bv) computed on (hi, lo) fp16 pairs (three MFMAs per
+    product), returned as [nz, T, C] split storage (int32 carrier); streaming kernel ae_attn_split.hip (C = 512, T % 64 == 0)"""
+    lib = _lib.load()
+    nz, T, C = q.shape
+    qs, ks = convert(q.contiguous(), SPLIT), convert(k.contiguous(), SPLIT)
+    vts = convert(v.transpose(1, 2).contiguous(), SPLIT)      # [nz, C, T]: rows [T hi | T lo]
+    bd = bv.to(q.device, torch.float32).contiguous() if bv is not None else None
+    o = torch.empty(nz, T, C, device=q.device, dtype=torch.int32)
+    rc = lib.rs_op_ae_flash_attention_split(qs.data_ptr(), ks.data_ptr(), vts.data_ptr(), bd.data_ptr() if bd is not None else None, o.data_ptr(),
+                                            nz, T, C, _lib.current_stream_ptr())
+    _lib.check(rc, "rs_op_ae_flash_attention_split")
+    return o
+
+
 def split_pack_rows(w):
     """[rows, K] float weights -> the split-storage operand [rows][K hi | K lo] fp16 (hi = fp16(w), lo = fp16((w - hi) 2^11))"""
     w = w.detach().float()

@@ -607,6 +607,26 @@ def test_ae_flash_attention(gpu, nz, T, C):
     _close(o, ref, 3e-3, f"streaming AE attention nz={nz} T={T} C={C}")
 
 
+@pytest.mark.parametrize("nz,T", [(1, 64), (2, 256), (1, 4096)])
+def test_ae_flash_attention_split(gpu, nz, T):
+    """ae_flash_attn_split_kernel (round 4): the AttnBlock's softmax(q k^T / sqrt(C)) v + b_v (ldm/modules/diffusionmodules/model.py:179-203) on
+    (hi, lo) fp16 pairs with S kept on chip - 64 queries per workgroup, the channel range split over two waves, 32-key blocks - against
+    torch float64 on the same fp32 operands: the split pair carries 22 mantissa bits, the result must be fp32-class (<= 3e-6 relative)."""
+    from resshift_amd import ops
+
+    C = 512
+    g = torch.Generator().manual_seed(T)
+    q = torch.randn(nz, T, C, generator=g) * 1.5
+    k = torch.randn(nz, T, C, generator=g) * 1.5
+    v = torch.randn(nz, T, C, generator=g)
+    bv = torch.randn(C, generator=g) * 0.3
+    o = ops.ae_flash_attention_split(q.to(gpu), k.to(gpu), v.to(gpu), bv)
+    torch.cuda.synchronize()
+    w = torch.softmax(torch.bmm(q.double(), k.double().transpose(1, 2)) * C ** -0.5, dim=2)
+    ref = torch.bmm(w, v.double()) + bv.double()
+    _close(_unsplit(o), ref, 3e-6, f"split streaming AE attention nz={nz} T={T}")
+
+
 def test_gemm_nt_batched_and_softmax_split(gpu):
     """AE mid-block attention in split storage: S = q k^T (fp32 out), softmax -> split P, o = P v + b"""
     from resshift_amd import ops
