@@ -233,6 +233,7 @@ struct IGemmParams {
     unsigned x_bytes, w_bytes;  // extents of the x0 / w buffers for the igemm2 buffer descriptors (filled in by its launcher)
     int sh_howo, sh_wo;         // log2(Ho*Wo), log2(Wo) when both are powers of two, else -1 (filled in by the igemm2 launcher)
     int dbg;                    // timing ablations (RS_IGEMM_DBG): 1 = no operand loads after the prologue, 2 = no ds_read/MFMA, 4 = no barriers
+    int no_halo;                // 1: never the halo kernel (split storage: it scales the hi weight fragment by 2^11 - a layer with |w| >= 30 takes igemm_split)
     // fused input transform (halo kernel igemm4.hip only): x is the RAW tensor; act_in(x * xcoef[b][0][c] + xcoef[b][1][c]),
     // rounded to the storage type, is what the convolution sees (GroupNorm affine [B][2][C0] of GNParams::coef + SiLU)
     const float* xcoef;

@@ -775,7 +775,7 @@ struct rs_engine {
     // slices over the stage sequence, igemm4_kernel.h; `seg`: its tile geometry, 8 = four 8 x 8 images per tile)
     bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res, int* sk = nullptr, int* seg = nullptr) const {
         if (w.direct || (x.dt != RS_F16 && x.dt != RS_F16S) || y.dt != x.dt || x.C != w.CinP) return false;
-        if (x.dt == RS_F16S && big(w)) return false;   // |w| >= 30: no 2^11 scaling of the hi fragment - the generic split kernel takes it
+        if (x.dt == RS_F16S && big(w)) return false;   // |w| >= 30: no 2^11 scaling of the hi fragment - the generic split kernel takes it (conv(): IGemmParams::no_halo)
         const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
         int tw, bc, sg = 0, k = 1;
         if (!rs_igemm4_plan(&p, x.dt, y.dt, 1, &tw, &bc, &sg, &k)) return false;
@@ -821,6 +821,7 @@ struct rs_engine {
             ex.check(rs_direct_conv_launch(&p, x.dt, y.dt, ex.st), "direct_conv");
         } else {
             IGemmParams p = conv_params(w, x, x1, y, stride, pad_t, pad_l, up, act, res, out_scale);
+            p.no_halo = (x.dt == RS_F16S && big(w)) ? 1 : 0;   // (the launcher picks the kernel from the parameter block: tell it what halo_conv() decided)
             p.splitk = splitk; p.partial = partial;
             p.xcoef = xcoef; p.xact = xact;
             if (y.st) {   // statistics for the consuming GroupNorm: the halo kernel's or the generic split kernel's epilogue (or their split-K reduce)

@@ -133,7 +133,7 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
     static const int sk_target = []() { const char* e = getenv("RS_IGEMM_V4_SKTARGET"); return e ? atoi(e) : 256; }();
     static const int sk_minst = []() { const char* e = getenv("RS_IGEMM_V4_SKMINSTAGES"); return e ? atoi(e) : 6; }();
     const IGemmParams& p = *pp;
-    if (in_dt != out_dt || nz != 1 || p.C1 != 0) return 0;
+    if (in_dt != out_dt || nz != 1 || p.C1 != 0 || p.no_halo) return 0;
     if (!((in_dt == RS_F16 && (on & 1)) || (in_dt == RS_F16S && (on & 2)))) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.up != 1 || p.Ho != p.Hs || p.Wo != p.Ws) return 0;
     // (fp16 storage fetches the residual as 16-byte row pieces: 8-channel alignment of its stride; the BASE alignment is checked at launch -
