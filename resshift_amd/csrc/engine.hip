@@ -39,6 +39,8 @@ int rs_igemm4_plan(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW,
 int rs_igemm4_stats_px(const IGemmParams* p, int in_dt);
 int rs_igemm_split_stats_px(const IGemmParams* p, int splitk);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
+int rs_head_conv_launch(const void* x, int in_dt, const float* coef_dev, const float* w_dev, const float* bias_dev, float* y, int B, int H, int W, int C,
+                        int ldx, int Cout, int ldy, hipStream_t st);
 int rs_groupnorm_launch(const GNParams* p, int dt, int apply_slabs, hipStream_t st);
 int rs_win_attn_launch(const WinAttnParams* p, int dt, hipStream_t st);
 int rs_softmax_rows_launch(const float* s, void* out, int out_dt, long long nrows, int ncols, long long lds_, long long ldo, hipStream_t st);
@@ -427,7 +429,9 @@ struct rs_engine {
     // 16-byte K chunks stay aligned (3/6-channel image and latent inputs become 8-channel tensors).  `force_direct`
     // keeps the scalar kernel for the fp32-in/fp32-out 1x1 quant convs and for two-source convs whose first source is
     // not chunk aligned.
-    ConvW add_conv(const std::string& prefix, int Cin, int Cout, int KH, int KW, bool has_bias = true, bool force_direct = false) {
+    // `head`: an output head (3x3, <= 4 output channels, Cin % 8 == 0): ALSO the fp32 [tap][Cin][Cout] form for the fused GroupNorm + SiLU +
+    // conv kernel (direct_conv.hip: gn_silu_head_conv_kernel)
+    ConvW add_conv(const std::string& prefix, int Cin, int Cout, int KH, int KW, bool has_bias = true, bool force_direct = false, bool head = false) {
         ConvW c; c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW;
         c.idx = conv_count++;
         if ((int)big_w.size() < conv_count) big_w.resize(conv_count, 0);
@@ -492,6 +496,14 @@ struct rs_engine {
                                 o[(size_t)co * K + (size_t)t * CinP + ci] = w[((size_t)co * Cin + ci) * KH * KW + t];
                 });
         }
+        if (head && !c.direct && KH == 3 && KW == 3 && Cout <= 4 && (Cin % 8) == 0)
+            c.wd = (float*)blob.add(n * 4, [&](char* dst) {
+                const float* w = get(); if (!w) return;
+                float* o = (float*)dst;  // [tap][Cin][Cout]
+                for (int co = 0; co < Cout; ++co)
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int t = 0; t < 9; ++t) o[((size_t)t * Cin + ci) * Cout + co] = w[((size_t)co * Cin + ci) * 9 + t];
+            });
         if (has_bias) c.bias = add_f32(prefix + ".bias", Cout);
         return c;
     }
@@ -667,7 +679,7 @@ struct rs_engine {
             }
         }
         out_norm = add_gn("out.0", ch);
-        out_conv = add_conv("out.2", input_ch, u.out_channels, 3, 3);
+        out_conv = add_conv("out.2", input_ch, u.out_channels, 3, 3, true, false, /*head=*/true);
     }
     ResBlockW add_resnet(const std::string& p, int Cin, int Cout) {
         ResBlockW r; r.Cin = Cin; r.Cout = Cout;
@@ -712,7 +724,7 @@ struct rs_engine {
         enc_attn = add_attn("encoder.mid.attn_1", block_in);
         enc_mid2 = add_resnet("encoder.mid.block_2", block_in, block_in);
         enc_norm = add_gn("encoder.norm_out", block_in);
-        enc_out = add_conv("encoder.conv_out", block_in, a.z_channels, 3, 3);
+        enc_out = add_conv("encoder.conv_out", block_in, a.z_channels, 3, 3, true, false, /*head=*/true);
         quant_conv = add_conv("quant_conv", a.z_channels, a.embed_dim, 1, 1, true, /*force_direct=*/true);  // fp32 in / fp32 out
         // Decoder (model.py:550-660)
         post_quant_conv = add_conv("post_quant_conv", a.embed_dim, a.z_channels, 1, 1, true, /*force_direct=*/true);  // fp32 VQ output in
@@ -736,7 +748,7 @@ struct rs_engine {
             dec_levels[l] = L;
         }
         dec_norm = add_gn("decoder.norm_out", block_in);
-        dec_out = add_conv("decoder.conv_out", block_in, a.out_ch, 3, 3);
+        dec_out = add_conv("decoder.conv_out", block_in, a.out_ch, 3, 3, true, false, /*head=*/true);
         codebook = add_f32("quantize.embedding.weight", (size_t)a.n_embed * a.embed_dim);
     }
     size_t build(char* base, bool fill) {
@@ -883,6 +895,22 @@ struct rs_engine {
         View t = ex.T(X.B, X.H, X.W, X.C, X.dt);
         gn(ex, g, X, t, eps, RS_ACT_SILU, film);
         conv3(ex, w, t, Y, res);
+    }
+    // GroupNorm + SiLU + conv3x3 to <= 4 channels (the UNet's `out`, Encoder / Decoder norm_out + conv_out) -> fp32 NHWC `o`: one fused pass
+    // (gn_silu_head_conv_kernel) over the raw tensor with the GroupNorm as coefficients; RS_HEAD_FUSED=0 or a debug trace: normalise, then
+    // the implicit-GEMM conv (the round-3 path)
+    void head(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& o, float eps) {
+        static const bool fused = []() { const char* e = getenv("RS_HEAD_FUSED"); return !(e && e[0] == '0'); }();
+        if (fused && !ex.dbg && w.wd && !w.direct && o.dt == RS_F32 && X.C == w.Cin && (X.C % 8) == 0 && (X.ld % 8) == 0 && w.Cout <= 4) {
+            const float* coef = gn_coef(ex, g, X, eps, nullptr);
+            if (!ex.dry) ex.check(rs_head_conv_launch(X.p, X.dt, coef, w.wd, w.bias, (float*)o.p, X.B, X.H, X.W, X.C, X.ld, w.Cout, o.ld, ex.st), "head conv");
+            return;
+        }
+        const size_t mk = ex.mark();
+        View t = ex.T(X.B, X.H, X.W, X.C, X.dt);
+        gn(ex, g, X, t, eps, RS_ACT_SILU);
+        conv(ex, w, t, nullptr, o, 1, 1, 1, 1, 0, nullptr);
+        ex.reset(mk);
     }
     void conv1(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0) {
         conv(ex, w, x, nullptr, y, 1, 0, 0, 1, act, res);
@@ -1344,10 +1372,8 @@ struct rs_engine {
         }
         // ---- out head (unet.py:893-894)
         {
-            View t = ex.T(B, last.H, last.W, last.C, dt);
-            gn(ex, out_norm, last, t, 1e-5f, RS_ACT_SILU);
             View o = ex.T(B, H, W, u.out_channels, RS_F32);
-            conv(ex, out_conv, t, nullptr, o, 1, 1, 1, 1, 0, nullptr);
+            head(ex, out_norm, out_conv, last, o, 1e-5f);
             if (!ex.dry) ex.check(rs_nhwc_to_nchw_launch(o.p, RS_F32, out, B, u.out_channels, H * W, o.ld, 0, ex.st), "out->nchw");
         }
         ex.reset(mk0);
@@ -1399,10 +1425,8 @@ struct rs_engine {
         View m1 = ex.T(B, h.H, h.W, h.C, dt); resnet(ex, enc_mid1, h, m1);
         View m2 = ex.T(B, h.H, h.W, h.C, dt); attnblock(ex, enc_attn, m1, m2);
         View m3 = ex.T(B, h.H, h.W, h.C, dt); resnet(ex, enc_mid2, m2, m3);
-        View t = ex.T(B, h.H, h.W, h.C, dt);
-        gn(ex, enc_norm, m3, t, 1e-6f, RS_ACT_SILU);
         View zc = ex.T(B, h.H, h.W, a.z_channels, RS_F32);
-        conv(ex, enc_out, t, nullptr, zc, 1, 1, 1, 1, 0, nullptr);
+        head(ex, enc_norm, enc_out, m3, zc, 1e-6f);
         View zq = ex.T(B, h.H, h.W, a.embed_dim, RS_F32);
         conv(ex, quant_conv, zc, nullptr, zq, 1, 0, 0, 1, 0, nullptr);
         if (!ex.dry) ex.check(rs_nhwc_to_nchw_launch(zq.p, RS_F32, z_nchw, B, a.embed_dim, h.H * h.W, zq.ld, 0, ex.st), "z->nchw");
@@ -1442,10 +1466,8 @@ struct rs_engine {
                 h = y;
             }
         }
-        View t = ex.T(B, h.H, h.W, h.C, dt);
-        gn(ex, dec_norm, h, t, 1e-6f, RS_ACT_SILU);
         View o = ex.T(B, h.H, h.W, a.out_ch, RS_F32);
-        conv(ex, dec_out, t, nullptr, o, 1, 1, 1, 1, 0, nullptr);
+        head(ex, dec_norm, dec_out, h, o, 1e-6f);
         if (!ex.dry) ex.check(rs_nhwc_to_nchw_launch(o.p, RS_F32, img, B, a.out_ch, h.H * h.W, o.ld, 0, ex.st), "img->nchw");
         ex.reset(mk0);
     }

@@ -406,6 +406,7 @@ def test_tiled_path_tiles_larger_than_image_size(gpu, policy):
     tiles with stride 24, against the oracle's tiled restatement and the reference's own ImageSpliterTh + modules output."""
     from oracle import make_golden_offsize as mo
     from resshift_amd import ResShiftSampler
+    from resshift_amd.engine import parse_precision
 
     up, ap, dp, _ = H.CASES["tiny"]
     usd, asd = H.weights(up, ap)
@@ -416,7 +417,7 @@ def test_tiled_path_tiles_larger_than_image_size(gpu, policy):
     nbytes = s.engine.weight_blob().numel()
     with pytest.raises(RuntimeError, match="not packed"):   # a form that was not packed is refused loudly, not emulated
         s.engine.unet_forward(torch.zeros(1, up["in_channels"], 16, 16, device=gpu), [0], lq=torch.zeros(1, 3, 16, 16, device=gpu),
-                              prec="fp32" if policy == "parity" else "fp16")
+                              prec=parse_precision("fp32" if policy == "parity" else "fp16"))
     s_all = ResShiftSampler(_tiny_cfg(up, ap, dp), sf=4, use_amp=False, state_dicts={"model": usd, "autoencoder": asd}, pack="all")
     print(f"weight blob: {nbytes / 2**20:.1f} MiB for the {policy} policy, {s_all.engine.weight_blob().numel() / 2**20:.1f} MiB with every form")
     assert nbytes < 0.75 * s_all.engine.weight_blob().numel()
