@@ -39,9 +39,7 @@ __device__ __forceinline__ void mlp_stats(const f32x4 (&o)[FC2][2], float* ystat
     for (int i = 0; i < FC2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = o[i][0][r] + o[i][1][r], q = fmaf(o[i][0][r], o[i][0][r], o[i][1][r] * o[i][1][r]);
-#pragma unroll
-            for (int sh = 1; sh < 16; sh <<= 1) { a += __shfl_xor(a, sh); q += __shfl_xor(q, sh); }
+            const float a = rs_sum16(o[i][0][r] + o[i][1][r]), q = rs_sum16(fmaf(o[i][0][r], o[i][0][r], o[i][1][r] * o[i][1][r]));   // (DPP adds)
             if (lr == 0) { dst[(i * 16 + lg * 4 + r) * 2] = a; dst[(i * 16 + lg * 4 + r) * 2 + 1] = q; }
         }
 }

@@ -379,9 +379,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float a = s1[f][r], q = s2[f][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                const float a = rs_sum16(s1[f][r]), q = rs_sum16(s2[f][r]);   // (DPP adds: same bits as the xor-shuffle butterfly)
                 if (lr == 0) { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
             }
     }
