@@ -299,4 +299,7 @@ struct WinAttnParams {
     // projection epilogue (each wave owns 32 output features of ALL tokens of the window: a wave-local reduction, no atomics)
     float* ystats;
     int ystats_ld;
+    // GroupNorm tail (gn_tail.h; the split-storage fused kernel): the wave that publishes the image's last statistics also writes norm2's
+    // coefficients - every wave (head) of every window arrives once
+    GNTail tail;
 };

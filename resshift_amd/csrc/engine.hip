@@ -59,7 +59,7 @@ int rs_ae_flash_split_launch(const void* q, int ldq, const void* k, int ldk, con
                              float scale, hipStream_t st);
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
-                             int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, hipStream_t st);
+                             int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, const GNTail* tail, hipStream_t st);
 int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                        int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, hipStream_t st);
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
@@ -211,6 +211,18 @@ struct Exec {
     }
     unsigned* tickets(int n) { unsigned* q = ticket_base + ticket_used; ticket_used += (size_t)n; return q; }
     const TailPlan* tail_of(int prod) const { return (plan && prod >= 0 && prod < (int)plan->size() && (*plan)[prod].on) ? &(*plan)[prod] : nullptr; }
+    // the GNTail block of a producer's launch from its plan entry (real pass): the consuming GroupNorm's parameters, its coefficient slot, B
+    // fresh tickets and the other half of a concatenation; the launcher adds the arrival count and segment 0 (= this launch's statistics)
+    bool fill_tail(int prod, int B, GNTail& g) {
+        const TailPlan* t = tail_of(prod);
+        if (!t) return false;
+        t->drawn = true;
+        g.gamma = t->gamma; g.beta = t->beta; g.film = t->film; g.eps = t->eps;
+        g.coef = (float*)(pool_base + t->coef_off); g.ticket = tickets(B);
+        g.C = t->C; g.groups = 32; g.HW = t->HW;
+        if (t->two) { g.st1 = (const float*)(pool_base + t->st2_off); g.S1 = t->st2S; g.ld1 = t->st2ld; }
+        return true;
+    }
     bool used_split = false;   // a split-storage tensor was allocated: the call needs the split weights (checked after the dry run)
     View T(int B, int H, int W, int C, int dt) {
         if (dt == RS_F16S) used_split = true;
@@ -339,7 +351,7 @@ struct Exec {
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
     void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                   int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0, int dt = RS_F16, float* ystats = nullptr,
-                  int ystats_ld = 0) {
+                  int ystats_ld = 0, const GNTail* tail = nullptr) {
         const int sp = dt == RS_F16S;
         igemm_flops[sp ? 2 : 0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
         fam_note(sp ? F_SWINMLP_S : F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD, M, E, HD);
@@ -355,7 +367,7 @@ struct Exec {
             e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
             (void)hipEventRecord(e0, st);
         }
-        if (sp) check(rs_swin_mlp_split_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, ystats, ystats_ld, st), "swin_mlp_split");
+        if (sp) check(rs_swin_mlp_split_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, ystats, ystats_ld, tail, st), "swin_mlp_split");
         else check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, ystats, ystats_ld, st), "swin_mlp");
         if (e1) (void)hipEventRecord(e1, st);
     }
@@ -840,13 +852,7 @@ struct rs_engine {
                 const bool halo = !x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res);
                 if (halo || (!x1 && x.dt == RS_F16S && y.dt == RS_F16S)) { p.ystats = y.st; p.ystats_ld = y.stld; }
                 else { ex.err = -3; g_err = "output statistics requested from a conv whose kernel cannot produce them"; return; }
-                if (const TailPlan* t = ex.tail_of(y.st_prod)) {   // ... and that GroupNorm's coefficients too (gn_tail.h)
-                    t->drawn = true;
-                    p.tail.gamma = t->gamma; p.tail.beta = t->beta; p.tail.film = t->film; p.tail.eps = t->eps;
-                    p.tail.coef = (float*)(ex.pool_base + t->coef_off); p.tail.ticket = ex.tickets(y.B);
-                    p.tail.C = t->C; p.tail.groups = 32; p.tail.HW = t->HW;
-                    if (t->two) { p.tail.st1 = (const float*)(ex.pool_base + t->st2_off); p.tail.S1 = t->st2S; p.tail.ld1 = t->st2ld; }
-                }
+                (void)ex.fill_tail(y.st_prod, y.B, p.tail);   // ... and that GroupNorm's coefficients too (gn_tail.h)
             }
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
@@ -1047,14 +1053,28 @@ struct rs_engine {
             const bool fuse_proj = fuse_qkv && (X.dt == RS_F16S || (attn_fused >= 2 && s.proj.wh_frag));   // ... and the output projection + shortcut as well
             View a, e2;
             if (fuse_proj) e2 = ex.T(X.B, X.H, X.W, E, X.dt); else a = ex.T(X.B, X.H, X.W, E, X.dt);
-            // RS_GN_SWIN_STATS=1: the fused kernels' epilogues leave the statistics of their outputs for the GroupNorm that
-            // reads them (attention -> norm2: one partial set per window; MLP -> the next block's norm1: one per 32 tokens): no
-            // statistics pass over those tensors
-            // (default OFF: measured slower than the statistics passes it removes - fp16 153.2 -> 155.5 - 157.0 ms, parity 285.4 -> 287.8 ms
-            // per pass on one box, profiles/r3_negative_results.txt: those passes read tensors that are still resident in the 256 MB
-            // Infinity Cache, the epilogue reductions and the many-partial coefficient kernels cost as much)
+            // fp16 storage: one fused MLP launch, the [M][4E] hidden tensor never reaches HBM (swin_mlp.hip); RS_MLP_FUSED=0 or a
+            // small token count (RS_MLP_FUSED_MINM) keep the two GEMMs
+            static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 3; }();   // bit 0: fp16, bit 1: split storage
+            static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 16384; }();   // (8192 tokens: 32 us fused vs 14 + 15 us apart)
+            const int Mtok = X.B * X.H * X.W, HWt = X.H * X.W;
+            const bool fuse_mlp = mlp_fused && !big_mlp && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
+                                  s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.w_for(X.dt) && s.fc2.w_for(X.dt);
+            const bool fold2 = fuse_mlp && gn_fold && !ex.dbg && HWt % 128 == 0;
+            // The fused kernels' epilogues leave the statistics of their outputs for the GroupNorm that reads them (attention -> norm2: one
+            // partial set per window; MLP -> the next block's norm1: one per 128-token tile) and - round 4 - the launch that completes an
+            // image's statistics writes that GroupNorm's coefficients (tail): no pass over those tensors, no coefficient launch.
+            //   split storage: default on (RS_GN_SWIN_STATS_SPLIT=0: statistics pass + tail as for any tensor without producer statistics);
+            //   fp16 storage: RS_GN_SWIN_STATS=1 keeps the round-3 form (statistics only, coefficient kernel; measured slower than the passes
+            //   it removes, profiles/r3_negative_results.txt) - default off.
             static const bool swin_stats = []() { const char* v = getenv("RS_GN_SWIN_STATS"); return v && v[0] == '1'; }();
-            if (fuse_proj && swin_stats && !ex.dbg) {
+            static const bool swin_stats_split = []() { const char* v = getenv("RS_GN_SWIN_STATS_SPLIT"); return !(v && v[0] == '0'); }();
+            const bool sstats = X.dt == RS_F16S && swin_stats_split && !ex.dbg;
+            if (fuse_proj && sstats && fold2) {   // (only where norm2 is a coefficient-only GroupNorm: the fused MLP applies it)
+                e2.stS = (X.H / 8) * (X.W / 8); e2.stld = E;
+                e2.st = ex.pool((size_t)X.B * e2.stS * e2.stld * 2 * sizeof(float));
+                e2.st_prod = ex.prod_seq++;
+            } else if (fuse_proj && X.dt == RS_F16 && swin_stats && !ex.dbg) {
                 e2.stS = (X.H / 8) * (X.W / 8); e2.stld = e2.ld;
                 e2.st = (float*)ex.raw((size_t)X.B * e2.stS * e2.stld * 2 * sizeof(float));
             }
@@ -1066,7 +1086,8 @@ struct rs_engine {
                     if (fold1) { p.x = e.p; p.ldx = e.ld; p.xcoef = coef1; } else { p.x = n.p; p.ldx = n.ld; }
                     p.wqkv = s.qkv.w_frag_for(X.dt); p.bqkv = s.qkv.bias;
                     if (fuse_proj) { p.out = e2.p; p.ldo = e2.ld; p.wproj = s.proj.w_frag_for(X.dt); p.bproj = s.proj.bias; p.res = e.p; p.ldres = e.ld;
-                                     p.ystats = e2.st; p.ystats_ld = e2.stld; }
+                                     p.ystats = e2.st; p.ystats_ld = e2.stld;
+                                     if (e2.st) (void)ex.fill_tail(e2.st_prod, X.B, p.tail); }
                     else { p.out = a.p; p.ldo = a.ld; }
                     ex.win_attn_qkv(p, E, X.dt);
                 }
@@ -1083,29 +1104,27 @@ struct rs_engine {
             }
             ex.tr(bp + "proj", e2);
             View e3;
-            // fp16 storage: one fused launch, the [M][4E] hidden tensor never reaches HBM (swin_mlp.hip); RS_MLP_FUSED=0 or a
-            // small token count (RS_MLP_FUSED_MINM) keep the two GEMMs
-            static const int mlp_fused = []() { const char* v = getenv("RS_MLP_FUSED"); return v ? atoi(v) : 3; }();   // bit 0: fp16, bit 1: split storage
-            static const int mlp_minm = []() { const char* v = getenv("RS_MLP_FUSED_MINM"); return v ? atoi(v) : 16384; }();   // (8192 tokens: 32 us fused vs 14 + 15 us apart)
-            const int Mtok = X.B * X.H * X.W;
-            const bool fuse_mlp = mlp_fused && !big_mlp && (X.dt == RS_F16 || (X.dt == RS_F16S && (mlp_fused & 2))) && rs_swin_mlp_supported(E, s.fc1.Cout) &&
-                                  s.fc2.Cout == E && Mtok >= mlp_minm && s.fc1.w_for(X.dt) && s.fc2.w_for(X.dt);
-            const bool fold2 = fuse_mlp && gn_fold && !ex.dbg && (X.H * X.W) % 128 == 0;
             View n2;
             const float* coef2 = nullptr;
             if (fold2) coef2 = gn_coef(ex, s.n2, e2, 1e-5f, nullptr);
             else { n2 = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE); }
             if (fuse_mlp) {
                 e3 = ex.T(X.B, X.H, X.W, E, X.dt);
-                const int HWt = X.H * X.W;
-                if (swin_stats && !ex.dbg && HWt % 32 == 0 && Mtok % 32 == 0) {   // consumed by the next block's norm1 (if any)
+                const bool is_last = &s == &b.blocks.back();   // (the last block's output feeds patch_unembed, not a GroupNorm)
+                if (sstats && !is_last && HWt % 128 == 0 && Mtok % 128 == 0) {
+                    e3.stS = HWt / 128; e3.stld = E;
+                    e3.st = ex.pool((size_t)X.B * e3.stS * e3.stld * 2 * sizeof(float));
+                    e3.st_prod = ex.prod_seq++;
+                } else if (X.dt == RS_F16 && swin_stats && !ex.dbg && HWt % 32 == 0 && Mtok % 32 == 0) {   // consumed by the next block's norm1 (if any)
                     e3.stS = HWt / 32; e3.stld = e3.ld;
                     e3.st = (float*)ex.raw((size_t)X.B * e3.stS * e3.stld * 2 * sizeof(float));
                 }
                 if (!ex.dry) {
                     const void* w1 = s.fc1.w_for(X.dt); const void* w2 = s.fc2.w_for(X.dt);
-                    if (fold2) ex.swin_mlp(e2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, e2.ld, e2.ld, e3.ld, E, s.fc1.Cout, coef2, HWt, X.dt, e3.st, e3.stld);
-                    else ex.swin_mlp(n2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout, nullptr, HWt, X.dt, e3.st, e3.stld);
+                    GNTail tl{};
+                    const GNTail* tlp = (e3.st && ex.fill_tail(e3.st_prod, X.B, tl)) ? &tl : nullptr;
+                    if (fold2) ex.swin_mlp(e2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, e2.ld, e2.ld, e3.ld, E, s.fc1.Cout, coef2, HWt, X.dt, e3.st, e3.stld, tlp);
+                    else ex.swin_mlp(n2.p, w1, s.fc1.bias, w2, s.fc2.bias, e2.p, e3.p, Mtok, n2.ld, e2.ld, e3.ld, E, s.fc1.Cout, nullptr, HWt, X.dt, e3.st, e3.stld, tlp);
                 }
             } else {
                 View f = ex.T(X.B, X.H, X.W, s.fc1.Cout, X.dt);
@@ -2137,7 +2156,7 @@ int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const
 }
 int rs_op_swin_mlp_split(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
                          int M, int E, int HD, void* stream) {
-    const int rc = rs_swin_mlp_split_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    const int rc = rs_swin_mlp_split_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, nullptr, 0, nullptr, (hipStream_t)stream);
     if (rc) fail("swin_mlp_split launch rejected the shape (split storage, E = 192, HD = 768 only)");
     return rc;
 }

@@ -16,6 +16,7 @@
 // 146 us for this kernel at 131072 tokens: every wave then reads the whole W1 and W2 chunk from LDS, 72 LDS instructions
 // per chunk per wave.  profiles/r1_igemm_ablation.txt.)
 #include "igemm_common.h"
+#include "gn_tail.h"
 #include <type_traits>
 #include <cstdlib>
 
@@ -307,8 +308,9 @@ struct MlpSplitParams {
     int M, ldx, ldres, ldy;
     const float* xcoef;   // optional GroupNorm affine [B][2][E]: x is the raw tensor, normalised (joined value) while it is loaded
     int HW;
-    float* ystats;        // optional output statistics, as MlpParams::ystats
-    int ystats_ld;
+    float* ystats;        // optional output statistics: [B][HW / 128][ystats_ld][2] floats, one set per workgroup tile (128 tokens of one image:
+    int ystats_ld;        // HW % 128 == 0, M % 128 == 0) - sum / sum of squares per channel, for the GroupNorm that consumes y (the next block's norm1)
+    GNTail tail;          // ... and with tail.coef that GroupNorm's coefficients too (gn_tail.h)
 };
 
 template <int E, int HD>
@@ -478,7 +480,35 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
             o[i][j] = v;
         }
     }
-    if (p.ystats && m0 + wp * 32 < p.M) mlp_stats<FC2>(o, p.ystats, p.ystats_ld, m0 + wp * 32, p.HW, wc * (E / 2), lr, lg);
+    // Output statistics (one set per 128-token tile): the waves' per-channel sums over their 32 tokens meet in LDS behind the staging tiles,
+    // wave 0 adds the four token-waves in a fixed order, publishes the tile's pairs and - GroupNorm tail - draws the image's ticket while the
+    // other waves are already storing (gn_tail.h)
+    float* const sb = (float*)(smem + 8 * 32 * ROWB);                 // [8 waves][E / 2][2]
+    unsigned* const tail_flag = (unsigned*)(sb + 8 * (E / 2) * 2);
+    const bool tail_on = p.ystats != nullptr && p.tail.coef != nullptr;
+    const int img = m0 / (p.HW > 0 ? p.HW : 1);
+    if (p.ystats) {
+#pragma unroll
+        for (int i = 0; i < FC2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = rs_sum16(o[i][0][r] + o[i][1][r]), q = rs_sum16(fmaf(o[i][0][r], o[i][0][r], o[i][1][r] * o[i][1][r]));
+                if (lr == 0) { sb[(wave * (E / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (E / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
+            }
+        __syncthreads();
+        if (wave == 0) {
+            float* dst = p.ystats + (((long long)img * (p.HW >> 7) + ((m0 - img * p.HW) >> 7)) * p.ystats_ld) * 2;
+            for (int c = lane; c < E; c += 64) {
+                const int hw_ = c / (E / 2), cl = c - hw_ * (E / 2);   // channel-wave, channel inside its half
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (E / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (E / 2) + cl) * 2 + 1]; }
+                if (tail_on) rs_pub_pair(dst + c * 2, a, q);
+                else { dst[c * 2] = a; dst[c * 2 + 1] = q; }
+            }
+            if (tail_on) { const bool last = rs_gn_tail_arrive(p.tail, img); if (lane == 0) *tail_flag = last ? 1u : 0u; }
+        }
+    }
     RS_MLP_STAMP(5);
     constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
 #pragma unroll
@@ -502,6 +532,10 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
     }
     RS_MLP_STAMP(6);
+    if (tail_on) {   // (kernel-uniform) behind this barrier the LDS is free: the image's last workgroup turns the tile partials into coefficients
+        __syncthreads();
+        if (*tail_flag) rs_gn_tail_finish<512>(p.tail, img, (float*)smem);
+    }
 }
 
 }  // namespace
@@ -524,13 +558,19 @@ extern "C" int rs_mlp_phase_cycles(int nwg, double* out6) {
 // split storage: x / res / y tensors of (hi, lo) pairs, w1 / w2 packed [rows][K hi | K lo]
 extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
                                         int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld,
-                                        hipStream_t st) {
-    if (ystats && (HW <= 0 || (HW & 31) || (M & 31))) return -2;
+                                        const GNTail* tail, hipStream_t st) {
+    if (ystats && (HW <= 0 || (HW & 127) || (M & 127))) return -2;   // one statistics set per 128-token tile of one image
+    if (tail && tail->coef && !ystats) return -2;
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
     if (xcoef && (HW <= 0 || HW % 128)) return -2;
     MlpSplitParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
     p.M = M; p.ldx = ldx; p.ldres = ldres; p.ldy = ldy; p.xcoef = xcoef; p.HW = HW; p.ystats = ystats; p.ystats_ld = ystats_ld;
+    if (tail && tail->coef) {   // GroupNorm tail: this launch's statistics are segment 0; every 128-token tile of an image arrives once
+        p.tail = *tail;
+        p.tail.expected = HW / 128;
+        p.tail.st0 = ystats; p.tail.S0 = HW / 128; p.tail.ld0 = ystats_ld; p.tail.n0 = E;
+    }
     constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
     static RsAttrFlags attr_flags;
     if (attr_flags.need()) {

@@ -16,6 +16,7 @@
 //   4. the heads' results meet in LDS (the token tile's space, same format) and wave h produces output features 32h .. 32h + 31 of
 //      the projection, adds the shortcut and stores the (hi, lo) pair.
 #include "common.h"
+#include "gn_tail.h"
 #include <type_traits>
 
 namespace {
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     // residual / output tile (fused projection only; hi plane, lo plane in the token tile format): the shortcut's rows arrive by LDS-DMA,
     // the projection adds its result in place and the finished tile leaves as whole 128-byte lines
     char* const rt = smem + 2 * XS_PLANE + 6 * VT_HEAD * 2 + 5632;
+    // (GroupNorm tail: one LDS word in the slack behind the bias table says whether a wave of this workgroup drew the image's last ticket)
+    unsigned* const tail_flag = (unsigned*)(btab + 1404);
+    const bool tail_on = p.tail.coef != nullptr && p.ystats != nullptr;
+    if (tid == 0) *tail_flag = 0u;
     for (int e = tid; e < 6 * 225; e += 384) {
         const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
         const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
@@ -380,8 +385,14 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = rs_sum16(s1[f][r]), q = rs_sum16(s2[f][r]);   // (DPP adds: same bits as the xor-shuffle butterfly)
-                if (lr == 0) { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
+                if (lr == 0) {
+                    if (tail_on) rs_pub_pair(dst + (16 * f + 4 * lg + r) * 2, a, q);   // write-through: read by the image's last arriver inside this launch
+                    else { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
+                }
             }
+        // GroupNorm tail (gn_tail.h): this wave (head) has published its 32 channels of the window: it arrives on its own - nobody waits -
+        // and if it drew the image's last ticket the workgroup computes norm2's coefficients at the very end
+        if (tail_on && rs_gn_tail_arrive(p.tail, b) && lane == 0) *tail_flag = 1u;
     }
     __syncthreads();   // the output tile is complete
     // whole rows out: 2 planes x 24 pieces of 8 token rows x 128 B (8 full cache lines per wave instruction), 8 per wave
@@ -395,6 +406,10 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
         }
     }
     RS_ATTN_STAMP(10);
+    if (tail_on) {   // (kernel-uniform) behind this barrier the LDS is free: the image's last workgroup turns the window partials into coefficients
+        __syncthreads();
+        if (*tail_flag) rs_gn_tail_finish<384>(p.tail, b, (float*)smem);
+    }
 }
 
 }  // namespace
@@ -433,6 +448,12 @@ extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t
     const size_t lds = lds_max - (p.wproj ? 0 : (size_t)2 * 3 * 64 * 128);
     static RsAttrFlags attr_flags;
     if (attr_flags.need()) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); }
-    hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
+    WinAttnParams q = p;
+    if (q.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every wave (head) of every window of an image arrives once
+        if (!q.ystats || !q.wproj) return -2;
+        q.tail.expected = nwin * p.heads;
+        q.tail.st0 = q.ystats; q.tail.S0 = nwin; q.tail.ld0 = q.ystats_ld; q.tail.n0 = 32 * p.heads;
+    }
+    hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, q, (unsigned)xb, (unsigned)rb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
