@@ -378,23 +378,30 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             *(f16x4*)cell = hv;
             *(f16x4*)(cell + XS_PLANE) = lv;
         }
-    if (p.ystats) {   // statistics for norm2: the wave holds its 32 features of all 64 tokens of the window
-        float* dst = p.ystats + (((long long)b * (nwx * (H / WS)) + blockIdx.x) * p.ystats_ld + h * HD) * 2;
+    // Statistics for norm2 (and, with WinAttnParams::tail, its coefficients: gn_tail.h): every wave holds its 32 features of all 64 tokens
+    // of the window; the six waves' sums meet in LDS (the V^T space: dead since the projection began), wave 0 alone publishes the window's
+    // 192 pairs and draws ONE ticket per window behind the barrier that completes the output tile - the other waves go on to the stores.
+    // (A ticket per wave - 384 arrivals per image on one address - cost the kernel 24 us per launch: same-address atomics serialise.)
+    float* const st_lds = (float*)(smem + 2 * XS_PLANE);
+    if (p.ystats) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = rs_sum16(s1[f][r]), q = rs_sum16(s2[f][r]);   // (DPP adds: same bits as the xor-shuffle butterfly)
-                if (lr == 0) {
-                    if (tail_on) rs_pub_pair(dst + (16 * f + 4 * lg + r) * 2, a, q);   // write-through: read by the image's last arriver inside this launch
-                    else { dst[(16 * f + 4 * lg + r) * 2] = a; dst[(16 * f + 4 * lg + r) * 2 + 1] = q; }
-                }
+                if (lr == 0) { st_lds[(h * HD + 16 * f + 4 * lg + r) * 2] = a; st_lds[(h * HD + 16 * f + 4 * lg + r) * 2 + 1] = q; }
             }
-        // GroupNorm tail (gn_tail.h): this wave (head) has published its 32 channels of the window: it arrives on its own - nobody waits -
-        // and if it drew the image's last ticket the workgroup computes norm2's coefficients at the very end
+    }
+    __syncthreads();   // the output tile is complete (and the window's statistics are in LDS)
+    if (p.ystats && h == 0) {
+        float* dst = p.ystats + (((long long)b * (nwx * (H / WS)) + blockIdx.x) * p.ystats_ld) * 2;
+        for (int c = lane; c < E; c += 64) {
+            const float a = st_lds[2 * c], q = st_lds[2 * c + 1];
+            if (tail_on) rs_pub_pair(dst + 2 * c, a, q);   // write-through: read by the image's last arriver inside this launch
+            else { dst[2 * c] = a; dst[2 * c + 1] = q; }
+        }
         if (tail_on && rs_gn_tail_arrive(p.tail, b) && lane == 0) *tail_flag = 1u;
     }
-    __syncthreads();   // the output tile is complete
     // whole rows out: 2 planes x 24 pieces of 8 token rows x 128 B (8 full cache lines per wave instruction), 8 per wave
     {
         const int rsub = lane >> 3, ps = lane & 7, chunk = ps ^ (rsub & 7);
@@ -449,9 +456,9 @@ extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t
     static RsAttrFlags attr_flags;
     if (attr_flags.need()) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); }
     WinAttnParams q = p;
-    if (q.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every wave (head) of every window of an image arrives once
+    if (q.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every window of an image arrives once
         if (!q.ystats || !q.wproj) return -2;
-        q.tail.expected = nwin * p.heads;
+        q.tail.expected = nwin;   // (wave 0 of every window's workgroup arrives once)
         q.tail.st0 = q.ystats; q.tail.S0 = nwin; q.tail.ld0 = q.ystats_ld; q.tail.n0 = 32 * p.heads;
     }
     hipLaunchKernelGGL(win_attn_qkv_split_kernel, dim3(nwin, p.B), dim3(64 * p.heads), lds, st, q, (unsigned)xb, (unsigned)rb);

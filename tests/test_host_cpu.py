@@ -366,7 +366,7 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     executed by its real pass; the two walk the same control flow and must agree about every pool they size: coefficient pool, tickets,
     producer and GroupNorm sequence numbers - and every planned tail must be attached to its producer's launch.  RS_FAKE_DEVICE=1 lets the
     real pass run on a host-memory arena in this GPU-less container (every launch fails, the bookkeeping does not).  Also pins the
-    launch diet of the round: <= 3 000 kernel launches per batch-32 parity pass (4 609)."""
+    launch diet of the round: <= 2 800 kernel launches per batch-32 parity pass (4 609 by the old count, 4 155 kernels in the trace)."""
     import re
     import subprocess
     import sys
@@ -381,4 +381,4 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     assert "never attached" not in r.stderr and "disagree" not in r.stdout, (r.stdout[-500:], r.stderr[-500:])
     assert v[0] > 0 and v[1] > 0          # tails were planned at all
     if cname.startswith("realsr") and B == 32 and prec == 2:
-        assert v[8] <= 3000, v[8]
+        assert v[8] <= 2800, v[8]
