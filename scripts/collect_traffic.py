@@ -28,6 +28,20 @@ gw, gnw = total(sys.argv[2], "WRITE_SIZE", GN)
 out["groupnorm"] = {"kernel_family": " / ".join(GN), "launches_fetch_pass": gnf, "launches_write_pass": gnw,
                     "fetch_bytes_per_launch": 2.0 * gf * 1024 / max(1, gnf), "write_bytes_per_launch": gw * 1024 / max(1, gnw)}
 out["groupnorm"]["hbm_bytes_per_launch"] = out["groupnorm"]["fetch_bytes_per_launch"] + out["groupnorm"]["write_bytes_per_launch"]
+# per kernel instantiation of both families (attribute the traffic): launches, HBM MB fetched (x2 corrected) / written per launch
+import re
+def per_kernel(path, counter, scale):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter: continue
+        n = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"]).strip()
+        if not any(k in n for k in ("igemm", "swin_mlp", "win_attn", "ae_flash", "gn_", "splitk_reduce", "head_conv")): continue
+        a = acc.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"]) * 1024 * scale
+    return acc
+pf, pw = per_kernel(sys.argv[1], "FETCH_SIZE", 2.0), per_kernel(sys.argv[2], "WRITE_SIZE", 1.0)
+out["per_kernel"] = {n: {"launches": pf[n][0], "fetch_mb_per_launch": round(pf[n][1] / pf[n][0] / 1e6, 3),
+                         "write_mb_per_launch": round(pw.get(n, [1, 0.0])[1] / max(1, pw.get(n, [1, 0.0])[0]) / 1e6, 3),
+                         "total_gb": round((pf[n][1] + pw.get(n, [0, 0.0])[1]) / 1e9, 3)} for n in sorted(pf, key=lambda k: -(pf[k][1] + pw.get(k, [0, 0.0])[1]))}
 out["kernel_source_digest"] = _b._digest()[:16]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
