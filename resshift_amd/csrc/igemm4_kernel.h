@@ -111,7 +111,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // ---- tile decode: channel tiles of one pixel tile are adjacent (they share the halo in L2)
     const int nby = (p.Cout + BC - 1) / BC;
     const int txb_n = p.Wo / TW, tyb_n = p.Ho / TH;
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Small planes (SEG != 0, split-K over stage ranges): the grid is one-dimensional, id = tile * splitk + slice, so that the hardware's
+    // round-robin of workgroup ids over the 8 XCDs puts the SLICES on the XCDs (splitk = 8: XCD z runs slice z of every tile) and a slice's
+    // share of the weight matrix (640 x 5760 x 4 B / 8 = 1.8 MB) stays in that XCD's 4 MB L2.  With the slices on grid.z every XCD owned
+    // whole tiles and fetched the WHOLE matrix: 283 MB of HBM / fabric reads per launch for 25 MB of operands (PMC, profiles/
+    // r4_pmc_traffic_parity.json: the 8 x 8 level's convs were fetch-bound on weight re-reads).
+    const int nslice = (SEG != 0 && p.splitk > 1) ? p.splitk : 1;
+    int tile = SEG != 0 ? (int)blockIdx.x / nslice : xcd_remap(blockIdx.x, gridDim.x);
     const int nb = tile % nby; tile /= nby;
     // SEG: one tile = four images of an 8 x 8 plane (SEG = 8) or one 16 x 16 image (SEG = 16); b = first image of the tile
     const int txb = SEG ? 0 : tile % txb_n;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // chunk stay ONE straight-line block - a per-tap range test costs the scheduler its view across the taps (measured: + 20 % on every
     // big-plane shape, profiles/r3_igemm4_phases.txt)
     constexpr bool SLICED = SEG != 0;
-    const int zsl = SLICED ? blockIdx.z : 0;
+    const int zsl = SLICED ? (int)blockIdx.x % nslice : 0;
     int s_beg = 0, s_end = nst;
     if (SLICED && p.splitk > 1) {
         const int per = (nst + p.splitk - 1) / p.splitk;
@@ -815,7 +821,8 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
 #undef RS_ABL4_CASE
     }
 #endif
-    hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>), dim3(tiles, 1, sk), dim3(64 * NWV), lds, st, p);
+    if (SEG != 0) hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>), dim3(tiles * sk), dim3(64 * NWV), lds, st, p);   // (id = tile * sk + slice: see the kernel)
+    else hipLaunchKernelGGL((igemm4_kernel<TW, BC, SPLIT, SEG, 0, NWV>), dim3(tiles, 1, sk), dim3(64 * NWV), lds, st, p);
     return hipGetLastError();
 }
 

@@ -25,3 +25,8 @@ done
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_fp16 -o fp16 -- python $R/bench.py --precision fp16 --steps 2 --warmup 1 $B > $O/trace_fp16.log 2>&1)
 db=$(ls $O/trace_fp16/*.db 2>/dev/null | head -1)
 if [ -n "$db" ]; then python scripts/rocpd_summary.py $db --top 24 > $O/kernel_trace_fp16.txt; rm -rf $O/trace_fp16; fi
+# the exact multi-GPU commands of BASELINE.json configs[4] / [2], as plumbing runs on this one-GPU box (ranks share the device: gloo)
+RESSHIFT_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 4 --config inpaint --steps 2 --warmup 1 --no-profile-pass > $O/bench_gpus4_inpaint.json 2> $O/bench_gpus4_inpaint.err; echo "gpus4 inpaint rc=$?"
+RESSHIFT_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --config journal --steps 2 --warmup 1 --no-profile-pass > $O/bench_gpus8_journal.json 2> $O/bench_gpus8_journal.err; echo "gpus8 journal rc=$?"
+for f in bench_gpus4_inpaint bench_gpus8_journal; do python -c "
+import json; d=json.load(open('$O/$f.json')); print('$f', d['n_gpus'], d['value'], d['ranks']['backend'], len(d['ranks']['per_rank']), d['ranks']['weight_broadcast_bytes'], d['other_policy_all_ranks'])"; done
