@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, final measurement call: rocprofv3 kernel trace + GroupNorm trace + PMC traffic of the parity pass on the FINAL sources (digest-stamped,
+# final measurement call of a round (gpurun --timeout 2400 -- bash scripts/gpu/final_measure.sh; outputs under gpurun_out/r4c12): rocprofv3 kernel trace + GroupNorm trace + PMC traffic of the parity pass on the FINAL sources (digest-stamped,
 # copied into profiles/ so that the bench line of the same call replays them), the per-shape table, then the full default bench line and the
 # other BASELINE configurations
 R=$(pwd); O=$R/gpurun_out/r4c12; mkdir -p $O; export TMPDIR=/tmp
