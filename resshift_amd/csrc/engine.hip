@@ -375,6 +375,17 @@ struct Exec {
 
 }  // namespace
 
+// RS_FAKE_DEVICE=1 is honoured only where there is NO HIP device (the build container): there the engine's real pass walks its control flow
+// on a host-memory arena while every launch fails - a CPU test compares its bookkeeping with the dry pass.  On a GPU box the variable is ignored.
+static bool rs_fake_device() {
+    static const bool fake = []() {
+        if (!getenv("RS_FAKE_DEVICE")) return false;
+        int n = 0;
+        return !(hipGetDeviceCount(&n) == hipSuccess && n > 0);
+    }();
+    return fake;
+}
+
 struct rs_engine {
     rs_config cfg;
     std::unordered_map<std::string, HostTensor> host;
@@ -1220,7 +1231,7 @@ struct rs_engine {
     const float* film_row(int t, hipStream_t st) {
         auto it = film_cache.find(t);
         if (it != film_cache.end()) return it->second;
-        if (getenv("RS_FAKE_DEVICE")) { film_cache[t] = (float*)malloc((size_t)film_total * 4); return film_cache[t]; }   // (plumbing check without a GPU, see run())
+        if (rs_fake_device()) { film_cache[t] = (float*)malloc((size_t)film_total * 4); return film_cache[t]; }   // (plumbing check without a GPU, see run())
         const int mc = cfg.unet.model_channels, half = mc / 2, emb_ch = 4 * mc;
         std::vector<float> e0(mc, 0.f);
         for (int k = 0; k < half; ++k) {
@@ -1511,7 +1522,7 @@ struct rs_engine {
         const size_t need = scratch_end + pool_bytes + ticket_bytes + 4096;
         // RS_FAKE_DEVICE=1 (plumbing check in a container without a GPU): the scratch arena comes from host memory and every launch simply
         // fails, but the real pass walks its whole control flow - enough to check that it agrees with the dry pass about pools and tickets
-        static const bool fake = getenv("RS_FAKE_DEVICE") != nullptr;
+        const bool fake = rs_fake_device();
         if (fake && need > arena.cap) { arena.base = (char*)malloc(64); arena.cap = (size_t)1 << 62; }
         if (need > arena.cap) {
             (void)hipStreamSynchronize(st);
@@ -1618,8 +1629,10 @@ rs_engine* rs_create(const rs_config* cfg) {
 
 void rs_destroy(rs_engine* e) {
     if (!e) return;
-    for (auto& kv : e->film_cache) (void)hipFree(kv.second);
-    if (e->arena.base) (void)hipFree(e->arena.base);
+    if (!rs_fake_device()) {
+        for (auto& kv : e->film_cache) (void)hipFree(kv.second);
+        if (e->arena.base) (void)hipFree(e->arena.base);
+    }
     delete e;
 }
 
@@ -1671,7 +1684,7 @@ int rs_pack_weights(rs_engine* e) {
 int rs_weights_ready(rs_engine* e) {
     if (!e || !e->bound) return fail("rs_weights_ready: bind a weight blob first");
     uint32_t flags = 0;   // header word of the blob (packed here, read from a cache file, or received by broadcast)
-    if (getenv("RS_FAKE_DEVICE")) { e->split_ok = true; e->ready = true; return 0; }   // (plumbing check without a GPU, see run())
+    if (rs_fake_device()) { e->split_ok = true; e->ready = true; return 0; }   // (plumbing check without a GPU, see run())
     if (hipMemcpy(&flags, e->blob.base, sizeof flags, hipMemcpyDeviceToHost) != hipSuccess) return fail("rs_weights_ready: cannot read the blob header");
     e->split_ok = (flags & 1u) != 0;
     if (e->conv_count > 0 && e->big_w_dev &&

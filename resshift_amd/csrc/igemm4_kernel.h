@@ -800,6 +800,7 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     p.w_bytes = (unsigned)wb;
     if (p.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every (pixel tile, channel tile) workgroup of an image arrives once
         if (!p.ystats || sk > 1 || SEG == 8) return hipErrorInvalidValue;   // (split-K slices / four-image tiles: the reduce kernel carries the tail)
+        if (p.tail.C > 2048 || p.tail.groups < 1 || p.tail.groups > 64 || (p.tail.C % p.tail.groups)) return hipErrorInvalidValue;   // (the finish's LDS scratch: 2 C + 2 groups floats)
         const int per_image = SEG == 16 ? 1 : (p.Ho / TH) * (p.Wo / TW);
         p.tail.expected = per_image * ((p.Cout + BC - 1) / BC);
         p.tail.st0 = p.ystats; p.tail.S0 = per_image; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;

@@ -529,6 +529,7 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
         else {
             if ((p.M % BP) || (hw % BP)) return hipErrorInvalidValue;   // whole tiles inside one image (rs_igemm_split_stats_px)
             if (p.tail.coef) {
+                if (p.tail.C > 2048 || p.tail.groups < 1 || p.tail.groups > 64 || (p.tail.C % p.tail.groups)) return hipErrorInvalidValue;   // (the finish's LDS scratch: 2 C + 2 groups floats)
                 p.tail.expected = (hw / BP) * ((p.Cout + BC - 1) / BC);
                 p.tail.st0 = p.ystats; p.tail.S0 = hw / BP; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
             }

@@ -3,6 +3,7 @@
 # copied into profiles/ so that the bench line of the same call replays them), the per-shape table, then the full default bench line and the
 # other BASELINE configurations
 R=$(pwd); O=$R/gpurun_out/r4c12; mkdir -p $O; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_engine_gpu.py -m gpu -q -x -k "groupnorm_tails or smoke or unet_forward_vs_oracle" > $O/pytest_quick.log 2>&1; echo "quick tests rc=$?"; tail -2 $O/pytest_quick.log
 B="--no-cpu-baseline --no-profile-pass --no-secondary"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_parity -o parity -- python $R/bench.py --steps 2 --warmup 1 $B > $O/trace_parity.log 2>&1)
 db=$(ls $O/trace_parity/*.db 2>/dev/null | head -1); echo "db=$db"

@@ -382,3 +382,20 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     assert v[0] > 0 and v[1] > 0          # tails were planned at all
     if cname.startswith("realsr") and B == 32 and prec == 2:
         assert v[8] <= 2800, v[8]
+
+
+def test_weight_forms_and_sampler_policies():
+    """Round 4: an engine packs only the weight forms its precision policy needs.  `sharding.weight_forms` maps the
+    policy's storage types to the rs_config enable flags; the sampler's policy table names the credited policy `parity` = split-precision
+    encoder + UNet (everything in front of the VQ argmin, ldm/modules/vqvae/quantize.py:276-285) + fp16 decoder."""
+    from resshift_amd import sharding
+    from resshift_amd.sampler import BaseSampler
+
+    assert sharding.weight_forms(None) == dict(enable_f16=True, enable_f32=True, enable_split=True)
+    assert sharding.weight_forms({"split", "fp16"}) == dict(enable_f16=True, enable_f32=False, enable_split=True)
+    assert sharding.weight_forms(["fp32"]) == dict(enable_f16=False, enable_f32=True, enable_split=False)
+    assert sharding.weight_forms(["fp16x3", "half"]) == dict(enable_f16=True, enable_f32=False, enable_split=True)   # aliases
+    assert BaseSampler.POLICIES["parity"] == ("split", "split", "fp16")
+    assert sharding.weight_forms(set(BaseSampler.POLICIES["parity"])) == dict(enable_f16=True, enable_f32=False, enable_split=True)
+    with pytest.raises(KeyError):
+        sharding.weight_forms(["fp8"])
