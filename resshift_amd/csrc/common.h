@@ -247,6 +247,14 @@ struct IGemmParams {
     // completes the statistics of y also writes the consuming GroupNorm's coefficients; the engine fills the GroupNorm's parameters, the
     // coefficient / ticket pointers and the other segment of a concatenation, the launcher the arrival count and segment 0 (= ystats)
     GNTail tail;
+    // folded 1x1 shortcut (halo kernel, split storage, 8-wave big-plane tiles only; models/unet.py:178-183,205-206 skip_connection,
+    // ldm/modules/diffusionmodules/model.py:121-127,148-149 nin_shortcut): y = conv3x3(act(gn(x0))) + bias + W_s sx + sbias.  The
+    // shortcut is sC more K columns of the SAME accumulator - centre-tap stages behind the nine taps' stages, fed from the RAW block
+    // input `sx` [B,Hs,Ws,(sld)] (no GroupNorm on those chunks) and the shortcut's split weights `sw` [Cout][sC hi | sC lo]: its
+    // GEMM launch, its output tensor and the residual read of that tensor disappear.  sx == null: none.
+    const void* sx; const void* sw; const float* sbias;
+    int sC, sld;
+    unsigned sx_bytes, sw_bytes;   // (filled in by the launcher)
 };
 
 struct DirectConvParams {

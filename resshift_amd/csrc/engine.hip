@@ -283,18 +283,19 @@ struct Exec {
         }
     }
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
-        igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz;
+        const int Kall = p.Ktot + (p.sx ? p.sC : 0);   // (+ the K columns of a folded 1x1 shortcut)
+        igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)Kall * (double)nz;
         {
             int tw, bc;
             const bool halo = rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw, &bc) != 0;
             const int f = in_dt == RS_F16 ? (halo ? F_HALO16 : F_IGEMM16) : (in_dt == RS_F16S ? (halo ? F_HALO_SPLIT : F_IGEMM_SPLIT) : F_IGEMM32);
-            fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)p.Ktot * (double)nz, p.M, p.Cout, p.Ktot, nz);
+            fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)Kall * (double)nz, p.M, p.Cout, Kall, nz);
         }
         {
             const double isz = in_dt == RS_F16 ? 2.0 : 4.0, osz = out_dt == RS_F16 ? 2.0 : 4.0;
-            const double src = (double)p.B * p.Hs * p.Ws * (double)(p.C0 + p.C1) * isz;
+            const double src = (double)p.B * p.Hs * p.Ws * (double)(p.C0 + p.C1 + (p.sx ? p.sC : 0)) * isz;
             const double out = (double)p.M * p.Cout * osz;
-            igemm_bytes += (double)nz * (src + (double)p.Cout * p.Ktot * isz + out + (p.res ? out : 0.0));
+            igemm_bytes += (double)nz * (src + (double)p.Cout * Kall * isz + out + (p.res ? out : 0.0));
         }
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -819,7 +820,8 @@ struct rs_engine {
         return true;
     }
     void conv(Exec& ex, const ConvW& w, const View& x, const View* x1, const View& y, int stride, int pad_t, int pad_l, int up,
-              int act, const View* res, float out_scale = 1.f, const float* xcoef = nullptr, int xact = RS_ACT_NONE) {
+              int act, const View* res, float out_scale = 1.f, const float* xcoef = nullptr, int xact = RS_ACT_NONE,
+              const ConvW* skw = nullptr, const View* skx = nullptr) {
         const int C1 = x1 ? x1->C : 0;
         // split-K for launches that cannot fill the chip (8x8 / 16x16 UNet levels): fp32 slabs live in the arena
         int splitk = 1;
@@ -859,6 +861,7 @@ struct rs_engine {
             p.no_halo = (x.dt == RS_F16S && big(w)) ? 1 : 0;   // (the launcher picks the kernel from the parameter block: tell it what halo_conv() decided)
             p.splitk = splitk; p.partial = partial;
             p.xcoef = xcoef; p.xact = xact;
+            if (skw) { p.sx = skx->p; p.sw = skw->ws; p.sbias = skw->bias; p.sC = skx->C; p.sld = skx->ld; }   // folded 1x1 shortcut (skip_fold())
             if (y.st) {   // statistics for the consuming GroupNorm: the halo kernel's or the generic split kernel's epilogue (or their split-K reduce)
                 const bool halo = !x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res);
                 if (halo || (!x1 && x.dt == RS_F16S && y.dt == RS_F16S)) { p.ystats = y.st; p.ystats_ld = y.stld; }
@@ -875,8 +878,19 @@ struct rs_engine {
         ex.check(e == hipSuccess ? 0 : -1, "memset");
     }
     void conv3(Exec& ex, const ConvW& w, const View& x, const View& y, const View* res = nullptr, int act = 0, const float* xcoef = nullptr,
-               int xact = RS_ACT_NONE) {
-        conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res, 1.f, xcoef, xact);
+               int xact = RS_ACT_NONE, const ConvW* skw = nullptr, const View* skx = nullptr) {
+        conv(ex, w, x, nullptr, y, 1, 1, 1, 1, act, res, 1.f, xcoef, xact, skw, skx);
+    }
+    // A ResBlock's 1x1 shortcut (models/unet.py:178-183,205-206; ldm/modules/diffusionmodules/model.py:121-127,148-149) as extra K columns
+    // of its second 3x3 conv (IGemmParams::sx) instead of a GEMM launch + a tensor + a residual read: split storage on the halo kernel's
+    // 8-wave big-plane tiles, whole 32-channel chunks of the block input, no weight that needs the unscaled path.  RS_SKIP_FOLD=0: off.
+    bool skip_fold(const Exec& ex, const ResBlockW& r, const View& X, const View& h1, const View& Y) const {
+        static const bool on = []() { const char* e = getenv("RS_SKIP_FOLD"); return !(e && e[0] == '0'); }();
+        static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
+        if (!on || !fold || ex.dbg || !r.has_skip || X.dt != RS_F16S || Y.dt != RS_F16S || big(r.skip) || big(r.c2)) return false;
+        if (!r.skip.ws || r.skip.KH != 1 || X.C != r.skip.CinP || (X.C % 32) || (X.ld % 8) || X.H != Y.H || X.W != Y.W) return false;
+        int sk = 1, seg = 0;
+        return halo_conv(r.c2, h1, Y, nullptr, &sk, &seg) && sk == 1 && seg == 0;
     }
     // Attach a statistics buffer to a tensor that is about to be produced by conv `w` from `x` (+res) IF its kernel can leave them: the halo
     // kernel (one partial set per 256- or 128-pixel tile of one image), the generic split-storage kernel (RS_GN_GEN_STATS, default on: one
@@ -902,13 +916,15 @@ struct rs_engine {
     // GroupNorm (+FiLM) + SiLU + 3x3 conv (models/unet.py:128-147,198-203; ldm/modules/diffusionmodules/model.py:129-147): on the
     // halo kernel the GroupNorm only produces per-(image, channel) affine coefficients and the conv applies them to the RAW tensor
     // in LDS (bit-identical to normalising first); otherwise normalise into a scratch tensor and convolve that
-    void gn_silu_conv3(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& Y, float eps, const float* film, const View* res) {
+    void gn_silu_conv3(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& Y, float eps, const float* film, const View* res,
+                       const ConvW* skw = nullptr, const View* skx = nullptr) {
         static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
         if (fold && !ex.dbg && halo_conv(w, X, Y, res)) {
             const float* coef = gn_coef(ex, g, X, eps, film);
-            conv3(ex, w, X, Y, res, 0, coef, RS_ACT_SILU);
+            conv3(ex, w, X, Y, res, 0, coef, RS_ACT_SILU, skw, skx);
             return;
         }
+        if (skw) { if (!ex.err) { ex.err = -3; g_err = "folded shortcut planned for a conv that does not run on the halo kernel"; } return; }
         View t = ex.T(X.B, X.H, X.W, X.C, X.dt);
         gn(ex, g, X, t, eps, RS_ACT_SILU, film);
         conv3(ex, w, t, Y, res);
@@ -1001,7 +1017,10 @@ struct rs_engine {
         gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-5f, nullptr, nullptr);
         ex.tr("conv1", h1);
         const float* film = film_row ? film_row + r.film_off : nullptr;
-        if (r.has_skip) {
+        if (skip_fold(ex, r, X, h1, Y)) {
+            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-5f, film, nullptr, &r.skip, &X);
+        } else if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
             conv1(ex, r.skip, X, sk);
             if (out_stats) want_stats(ex, r.c2, h1, Y, &sk);
@@ -1018,7 +1037,10 @@ struct rs_engine {
         View h1 = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
         want_stats(ex, r.c1, X, h1, nullptr);
         gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-6f, nullptr, nullptr);
-        if (r.has_skip) {
+        if (skip_fold(ex, r, X, h1, Y)) {
+            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr);
+            gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-6f, nullptr, nullptr, &r.skip, &X);
+        } else if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
             conv1(ex, r.skip, X, sk);
             if (out_stats) want_stats(ex, r.c2, h1, Y, &sk);

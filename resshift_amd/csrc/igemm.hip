@@ -425,7 +425,7 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
         int tw4 = 0, bc4 = 0;
         if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, in_dt, tw4, bc4, st);
-        if (p.xcoef) return -2;   // only the halo kernel applies an input transform: the caller must ask rs_igemm4_pick first
+        if (p.xcoef || p.sx) return -2;   // only the halo kernel applies an input transform / carries a folded shortcut: the caller must ask rs_igemm4_pick first
     }
     if (in_dt == RS_F16S) return rs_igemm_split_launch(&p, out_dt, nz, st);   // split storage: igemm_split.hip (single source)
     // second-generation kernel (LDS-DMA ring) for everything that fills the chip; RS_IGEMM_V2=0 forces the first one

@@ -156,11 +156,31 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // the K loop they push the kernel over 256 VGPRs, and a spilled value comes back through a scratch load - a VMEM access whose
     // wait also drains the DMA queue.
     const int Cout = p.Cout, Ktot = p.Ktot, ld0 = p.ld0;
+    // Folded 1x1 shortcut (IGemmParams::sx): chunks nch .. nch + nch2 - 1 of the halo sequence are 32-channel chunks of the RAW block
+    // input, stages 9 nch .. 9 nch + nch2 - 1 their centre-tap weight tiles [Cout][sC hi | sC lo] - the shortcut's GEMM as nch2 more
+    // stages of this accumulator.  Only in the instantiations the engine asks for it (split storage, big planes, 8 waves).
+    constexpr bool SKIPOK = SPLIT && SEG == 0 && NWV == 8 && ABL == 0;
+    const int nch = (Cin + KC - 1) / KC;
+    const int sC = (SKIPOK && p.sx) ? p.sC : 0, sld = p.sld;
+    const int nch2 = sC / KC, ncht = nch + nch2;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.sx, 0, p.sx_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.sw, 0, p.sw_bytes, 0x00020000);
     auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w + NWV, ...)
         if (wave + NWV * k >= XPIECES) return;                       // wave-uniform
         const int hr = 8 * (wave + NWV * k) + (lane >> 3);
         unsigned pix; int img;
         const bool inside = halo_src(hr, pix, img);
+        if constexpr (SKIPOK) {
+            // a chunk of the shortcut's source: same pixels, its own base / channel count / pixel pitch - SCALAR selects in front of the
+            // same vector code (a branch here would split the nine unrolled taps of the K loop into basic blocks: + 25 VGPRs, spills)
+            const bool sk = c >= nch;
+            const int cc = sk ? c - nch : c;
+            const unsigned ldc = (unsigned)(sk ? sld : ld0), Cc = (unsigned)(sk ? sC : Cin);
+            const unsigned cb = (unsigned)(cc * 32 + (kcp & 3) * 8);
+            const unsigned off = pix * ldc * 4u + (kcp >> 2) * ldc * 2u + cb * 2u;
+            lds_dma16(sk ? rsx : rx, smem + (c & 1) * XBUF + (wave + NWV * k) * 1024, (inside && cb < Cc) ? off : INV);
+            return;
+        }
         // source of LDS position (lane & 7) of this row = logical chunk kcp: fp16: channels 8 kcp ..; split: plane kcp >> 2
         // (0 = hi, 1 = lo, `ld0` halfs further in the pixel record), channels 8 (kcp & 3) ..
         const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
@@ -169,11 +189,28 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
         lds_dma16(rx, smem + (NXB == 2 ? (c & 1) * XBUF : 0) + (wave + NWV * k) * 1024, ok ? off : INV);
     };
     auto issue_w = [&](int s, int slot) {   // weight tile of stage s = (chunk s / 9, tap s % 9) -> ring slot s % NSLOT (passed in)
+        char* sbase = smem + WBASE + slot * WSLOT + (8 * wave) * 128;
+        if constexpr (SKIPOK) {
+            // stage s >= 9 nch: a tile of the shortcut's weights, rows [sC hi | sC lo] (scalar selects, see issue_x)
+            const bool sk = s >= 9 * nch;
+            const int c = sk ? nch + (s - 9 * nch) : s / 9, tap = sk ? 0 : s - c * 9;
+            const unsigned Kc = (unsigned)(sk ? sC : Ktot), Cc = (unsigned)(sk ? sC : Cin);
+            const unsigned cb = (unsigned)((sk ? c - nch : c) * 32 + (kcp & 3) * 8);
+            const unsigned kb = (unsigned)tap * Cc * 2u + cb * 2u + (kcp >> 2) * Kc * 2u;
+            const __amdgpu_buffer_rsrc_t rc = sk ? rsw : rw;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                if (RWP && i == RW - 1 && !wpart) continue;
+                const int n = n0 + RR * i + rr;
+                const bool ok = RR * i + rr < BC && n < Cout && cb < Cc;
+                lds_dma16(rc, sbase + (RR * i) * 128, ok ? (unsigned)n * Kc * 4u + kb : INV);
+            }
+            return;
+        }
         const int c = s / 9, tap = s - c * 9;
         const unsigned cb = SPLIT ? (unsigned)(c * 32 + (kcp & 3) * 8) : (unsigned)(c * 64 + kcp * 8);
         // weight rows: fp16 [K]; split [K hi | K lo]
         const unsigned kb = (unsigned)(tap * Cin) * 2u + cb * 2u + (SPLIT ? (kcp >> 2) * (unsigned)Ktot * 2u : 0u);
-        char* sbase = smem + WBASE + slot * WSLOT + (8 * wave) * 128;
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             if (RWP && i == RW - 1 && !wpart) continue;
@@ -313,7 +350,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     constexpr bool EARLY = false;
 #endif
     bool pre_applied = false;   // chunk c's halo was transformed during chunk c - 1
-    const int nch = (Cin + KC - 1) / KC, nst = nch * 9;
+    const int nst = nch * 9 + nch2;   // (+ the shortcut's centre-tap stages)
     // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
     // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
     // fragment register sets carried across the nine unrolled taps - igemm3's schedule - needs > 256 VGPRs here: 160 spilled
@@ -397,7 +434,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                         for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
                 }
             } else {
-                if (NXB == 2 && c + 1 < nch && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
+                if (NXB == 2 && c + 1 < ncht && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
             }
             // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
             if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
@@ -460,6 +497,54 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             } else compute();
         }
     }
+    if constexpr (SKIPOK) {
+        // The shortcut's stages: one per 32-channel chunk of the raw block input (no GroupNorm pass, the centre tap only).  The same ring
+        // discipline as above - stage s waits for tile s and chunk c (requested one / two stages ago), refills chunk c + 1 and tile
+        // s + NSLOT - 1 behind the barrier - except that a chunk lasts ONE stage, so all of a wave's halo pieces go out together.
+        for (int c = nch; c < ncht; ++c) {
+            const int s = 9 * nch + (c - nch);
+            if (NSLOT == 3 && s + 1 < nst) {
+                if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                const int flip = (c & 1) ? XBUF : -XBUF;
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) xfo[j][q] += flip;
+            }
+            if (c + 1 < ncht) {
+#pragma unroll
+                for (int k = 0; k < XPW; ++k) issue_x(c + 1, k);
+            }
+            // (the refills of a wave stay in the order halo pieces, then weight tile: the counted wait above relies on the tile being youngest)
+            if (s + NSLOT - 1 < nst) issue_w(s + NSLOT - 1, NSLOT == 3 ? (s + 2) % 3 : ((s + 1) & 1));
+            const char* wb = smem + WBASE + (NSLOT == 3 ? s % 3 : (s & 1)) * WSLOT + la;
+            f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                bh[j] = *(const f16x8*)(smem + xfo[j][1] + HWD * 128);
+                bl[j] = *(const f16x8*)(smem + xor64(xfo[j][1]) + HWD * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // exact (|w| < 30: the engine folds no shortcut with larger weights)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 2] = clock64();
 #endif
@@ -504,6 +589,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     for (int i = 0; i < FC; ++i) {
         const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
         bvs[i] = p.bias ? *(const f32x4*)(p.bias + min(n, p.Cout - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (SKIPOK && sC && p.sbias) bvs[i] += *(const f32x4*)(p.sbias + min(n, p.Cout - 4));   // (the shortcut's bias)
     }
     // per-channel statistics of the stored output for the consuming GroupNorm (IGemmParams::ystats): lane (lr, lg) accumulates its
     // 4 channels of every channel fragment over its FP pixel fragments, then the 16 `lr` lanes are reduced with xor-shuffles
@@ -798,6 +884,14 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     if (xb >= 0xF0000000ull || wb >= 0xF0000000ull) return hipErrorInvalidValue;  // 32-bit buffer offsets
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    if (p.sx) {   // folded 1x1 shortcut: only where the kernel carries it (see SKIPOK), whole 32-channel chunks, 16-byte rows
+        const size_t sxb = (size_t)p.B * p.Hs * p.Ws * p.sld * esz, swb = (size_t)p.Cout * p.sC * esz;
+        if (!SPLIT || SEG != 0 || NWV != 8 || sk > 1 || !p.sw || p.sC < 32 || (p.sC % 32) || (p.sld % 8) || p.sld < p.sC || sxb >= 0xF0000000ull ||
+            ((uintptr_t)p.sx & 15) || ((uintptr_t)p.sw & 15))
+            return hipErrorInvalidValue;
+        p.sx_bytes = (unsigned)sxb;
+        p.sw_bytes = (unsigned)swb;
+    } else { p.sC = 0; p.sx_bytes = p.sw_bytes = 0; }
     if (p.tail.coef) {   // GroupNorm tail: this launch's statistics are segment 0; every (pixel tile, channel tile) workgroup of an image arrives once
         if (!p.ystats || sk > 1 || SEG == 8) return hipErrorInvalidValue;   // (split-K slices / four-image tiles: the reduce kernel carries the tail)
         if (p.tail.C > 2048 || p.tail.groups < 1 || p.tail.groups > 64 || (p.tail.C % p.tail.groups)) return hipErrorInvalidValue;   // (the finish's LDS scratch: 2 C + 2 groups floats)
