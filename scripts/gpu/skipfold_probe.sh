@@ -1,5 +1,5 @@
 #!/bin/bash
-# Probe of the next-round patch scripts/probe/skipfold.patch (a ResBlock's 1x1 shortcut as extra K stages of its second 3x3 conv): the patched
+# (Record of the round-4 probe; the patch is in the tree since 60692e8.)  Probe of the shortcut fold (a ResBlock's 1x1 shortcut as extra K stages of its second 3x3 conv): the patched
 # library is built OUTSIDE the product path (scripts/probe/libresshift_skipfold.so, RESSHIFT_HIP_LIB) - the in-tree sources and their
 # digest-stamped profiles stay as committed.  (1) one UNet forward, fold on vs off; (2) A/B of the parity pass; (3) parity vs the CPU oracle.
 R=$(pwd); O=$R/gpurun_out/r4sf; mkdir -p $O; export TMPDIR=/tmp
