@@ -4,7 +4,7 @@
 # digest-stamped profiles stay as committed.  (1) one UNet forward, fold on vs off; (2) A/B of the parity pass; (3) parity vs the CPU oracle.
 R=$(pwd); O=$R/gpurun_out/r4sf; mkdir -p $O; export TMPDIR=/tmp
 export RESSHIFT_HIP_LIB=$R/scripts/probe/libresshift_skipfold.so
-for f in 1 0; do RS_TEST_PREC=split RS_TEST_META=1 RS_SKIP_FOLD=$f timeout 300 python tests/_unet_once.py $O/unet_$f.pt > $O/unet_$f.log 2>&1; echo "unet fold=$f rc=$?"; done
+for f in 1 0; do RS_TEST_PREC=split RS_TEST_META=1 RS_SKIP_FOLD=$f timeout 300 python tests/proc_unet_once.py $O/unet_$f.pt > $O/unet_$f.log 2>&1; echo "unet fold=$f rc=$?"; done
 python - <<PY
 import torch
 a=torch.load("$O/unet_1.pt"); b=torch.load("$O/unet_0.pt")

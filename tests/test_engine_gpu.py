@@ -581,7 +581,7 @@ def test_fused_swin_paths_match_unfused(gpu, tmp_path):
     def run(tag, **env):
         out = tmp_path / f"{tag}.pt"
         e = dict(os.environ, **{k: str(v) for k, v in env.items()})
-        subprocess.run([sys.executable, os.path.join(here, "_unet_once.py"), str(out)], check=True, env=e, timeout=300)
+        subprocess.run([sys.executable, os.path.join(here, "proc_unet_once.py"), str(out)], check=True, env=e, timeout=300)
         return torch.load(out)
 
     fused = run("fused")
@@ -610,7 +610,7 @@ def test_groupnorm_tails_change_no_bit(gpu, tmp_path, prec):
     def run(tag, **env):
         out = tmp_path / f"{tag}.pt"
         e = dict(os.environ, RS_TEST_META="1", RS_TEST_PREC=prec, RS_TEST_B="16", **{k: str(v) for k, v in env.items()})
-        subprocess.run([sys.executable, os.path.join(here, "_unet_once.py"), str(out)], check=True, env=e, timeout=600)
+        subprocess.run([sys.executable, os.path.join(here, "proc_unet_once.py"), str(out)], check=True, env=e, timeout=600)
         return torch.load(out)
 
     tail = run("tail")
@@ -637,7 +637,7 @@ def test_shortcut_fold_matches_the_separate_gemm(gpu, tmp_path):
     def run(tag, **env):
         out = tmp_path / f"{tag}.pt"
         e = dict(os.environ, RS_TEST_META="1", RS_TEST_PREC="split", RS_TEST_B="32", **{k: str(v) for k, v in env.items()})
-        subprocess.run([sys.executable, os.path.join(here, "_unet_once.py"), str(out)], check=True, env=e, timeout=600)
+        subprocess.run([sys.executable, os.path.join(here, "proc_unet_once.py"), str(out)], check=True, env=e, timeout=600)
         return torch.load(out)
 
     fold = run("fold")
@@ -909,7 +909,7 @@ def _ae_once(tmp_path, tag, which, side, prec, budget=None):
     if budget is not None:
         env["RS_ATTN_S_FLOATS"] = str(budget)
     here = os.path.dirname(os.path.abspath(__file__))
-    subprocess.run([sys.executable, os.path.join(here, "_ae_once.py"), str(out), which, str(side), prec], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, os.path.join(here, "proc_ae_once.py"), str(out), which, str(side), prec], check=True, env=env, timeout=600)
     return torch.load(out)
 
 
@@ -953,7 +953,7 @@ def test_streaming_ae_attention_vs_row_block_path(gpu, tmp_path):
     res = {}
     for name, fl in (("flash", "1"), ("rows", "0")):
         out = tmp_path / f"{name}.pt"
-        subprocess.run([sys.executable, os.path.join(here, "_ae_once.py"), str(out), "realsr", "1024", "fp16"], check=True,
+        subprocess.run([sys.executable, os.path.join(here, "proc_ae_once.py"), str(out), "realsr", "1024", "fp16"], check=True,
                        env=dict(os.environ, RS_AE_FLASH=fl), timeout=600)
         res[name] = torch.load(out)["z"]
     err = H.rel_err(res["flash"], res["rows"])
