@@ -21,17 +21,22 @@ Rank 0 prints ONE JSON line with the contract fields.  EVERYTHING at the top lev
 `roofline` (+ `per_kernel`, `groupnorm`, `traffic`), `cpu_baseline.gpu_vs_cpu_psnr_db` - describes ONE precision policy, the one
 `--precision` names.  The default is `parity` (split-precision encoder + UNet, fp16 decoder): the fastest policy that meets
 north_star's tolerance (image PSNR >= 60 dB against the reference CPU path).  Beside it:
-  * `roofline`      MFMA implicit-GEMM kernel family of the headline pass (hipEvent timed on the launch stream in a dedicated pass),
-                    `roofline.per_kernel` per kernel family, `roofline.groupnorm` the HBM-bound GroupNorm family, all live;
-                    `roofline.traffic` / `roofline.offline_rocprofv3` replay digest-stamped rocprofv3 results of this command from
+  * `roofline`      MFMA implicit-GEMM kernel family of the headline pass (hipEvent timed on the launch stream in a dedicated pass):
+                    `frac` = algorithmic flops / time / 2.5 PFLOP/s (`frac_whole_path` the same for the whole pass),
+                    `mfma_issue_frac` = matrix-pipe utilisation (split storage issues three MFMAs per product); `roofline.per_kernel` per
+                    kernel family, `roofline.groupnorm` the HBM-bound GroupNorm family, all live; `roofline.traffic` /
+                    `roofline.offline_rocprofv3` / `roofline.mfma_busy` replay digest-stamped rocprofv3 results of this command from
                     profiles/ (a process cannot attach rocprofv3 to itself) and say so;
-  * `cpu_baseline`  the CPU oracle timed on this host (N = 1 only, bounded sample: the first 8 images) + the unmodified reference modules'
-                    own number from profiles/ref_cpu_timing.json (build container; oracle/time_reference.py);
-  * `parity_vs_cpu_oracle`  image PSNR, latent PSNR and VQ code agreement of the headline policy against the CPU oracle on up to
+  * `ms_per_unet_step`  SURVEY.md 8(d)'s ms/step: one UNet forward + sampler update at the bench batch (hipEvents);
+  * `cpu_baseline`  the reference's OWN modules (kind "reference": the verified copy under oracle/_ref, made by oracle/make_ref_copy.py and
+                    shipped with the snapshot) timed on this host's cores (N = 1 only, bounded sample: the first 8 images); kind "port" =
+                    the oracle's restatement when the copy is absent;
+  * `parity_vs_cpu_oracle`  image PSNR, latent PSNR and VQ code agreement of the headline policy against that CPU run on up to
                     `--parity-images` (default: all 32) images of the batch, per-image minimum included;
   * `value_fp16_unqualified`  the all-fp16 policy (BASELINE.json's dtype) timed the same way, with ITS parity: fast, and below the tolerance;
-  * `torch_rocm_autocast_restatement_baseline`  the oracle's restatement of the reference run with stock PyTorch-ROCm ops on this GPU under
-                    torch.autocast(fp16) (what sampler.py:185 does) at the bench batch: its images/sec and ITS parity against the fp32 CPU path.
+  * `torch_rocm_autocast_baseline`  the reference's own modules moved to this GPU and run with stock PyTorch-ROCm ops under
+                    torch.autocast(fp16) (what sampler.py:185 does) at the bench batch: images/sec and ITS parity against the fp32 CPU path
+                    (`torch_rocm_autocast_restatement_baseline`: the oracle's restatement instead, when oracle/_ref is absent).
 """
 from __future__ import annotations
 
@@ -120,8 +125,12 @@ def per_kernel_rooflines(eng):
     fam_peak = [MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"],
                 MFMA_PEAK_TFLOPS["fp32"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["split"],
                 MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"]]
-    return [{"kernel": name, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
-             "frac": round(fl / (ms * 1e-3) / 1e12 / pk, 4), "ms_per_step": round(ms, 2), "launches_per_step": n}
+    # `frac` is SURVEY.md §8(d)'s: ALGORITHMIC flops / time / the dense fp16 MFMA peak (2.5 PFLOP/s) - a split-storage kernel issues three
+    # MFMAs per algorithmic product and is not credited for the two extra ones; `mfma_issue_frac` is the matrix-pipe utilisation (the
+    # same figure against the peak of the arithmetic the kernel actually issues: 2500 / 3 for split storage, 157.3 for fp32 MFMA)
+    return [{"kernel": name, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
+             "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["fp16"], 4), "mfma_issue_peak": round(pk, 1),
+             "mfma_issue_frac": round(fl / (ms * 1e-3) / 1e12 / pk, 4), "ms_per_step": round(ms, 2), "launches_per_step": n}
             for (name, fl, ms, n), pk in zip(eng.profile_families(), fam_peak) if n and ms > 0]
 
 
@@ -133,7 +142,7 @@ def psnr_db(a, b, p2p):
 def offline_profile(kind: str, precision: str, config: str, B: int):
     """digest-stamped rocprofv3 results of THIS command collected offline (scripts/collect_traffic.py / collect_gn_trace.py) - or
     (None, why) when the file is missing, was measured on other kernel sources, or for another workload"""
-    path = os.path.join(ROOT, "profiles", f"r4_{kind}_{precision}.json")
+    path = os.path.join(ROOT, "profiles", f"r5_{kind}_{precision}.json")
     if not (config == "realsr" and B == 32):
         return None, "offline rocprofv3 files exist for the default workload only"
     if not os.path.exists(path):
@@ -164,6 +173,7 @@ def main():
     ap.add_argument("--exact-leg", action="store_true", help="also run the fp32-policy parity/timing leg (one pass)")
     ap.add_argument("--no-exact-leg", action="store_true", help=argparse.SUPPRESS)   # (round-3 flag, now the default)
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
+    ap.add_argument("--no-reference-modules", action="store_true", help="baseline legs on the oracle's restatement even when oracle/_ref is present")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -301,9 +311,12 @@ def main():
             "bound": "mfma", "policy": pname,
             "kernel": "igemm4_kernel<*> (dominant: halo 3x3 conv) / igemm_split_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / "
                       "win_attn_qkv*_kernel / ae_flash_attn*_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
-            "achieved": round(achieved, 2), "peak": round(peak_eff, 1), "unit": "TFLOP/s", "frac": round(achieved / peak_eff, 4) if peak_eff else None,
-            "peak_note": "time-weighted dense MFMA peak of the arithmetic this policy runs: split storage = three fp16 MFMAs per product (2500 / 3), fp16 2500, fp32 157.3 TFLOP/s",
-            "frac_of_fp16_peak_algorithmic": round(achieved / MFMA_PEAK_TFLOPS["fp16"], 4),
+            "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS["fp16"], 4),
+            "frac_note": "SURVEY.md 8(d): algorithmic flops (2*M*N*K of the launches of the MFMA family) / their hipEvent time / 2.5 PFLOP/s dense fp16; "
+                         "the emulation's extra MFMAs (split storage: three per product) are NOT credited - that figure is mfma_issue_frac",
+            "mfma_issue_peak": round(peak_eff, 1), "mfma_issue_frac": round(achieved / peak_eff, 4) if peak_eff else None,
+            "mfma_issue_note": "matrix-pipe utilisation: against the time-weighted dense peak of the arithmetic this policy issues (split storage 2500 / 3, fp16 2500, fp32 157.3 TFLOP/s)",
+            "frac_whole_path": round(gflop_per_image * 1e9 * B / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["fp16"], 4),
             "traffic": None, "traffic_unit": "MB of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": None,
             "algorithmic_mb_per_launch": round(st["igemm_bytes"] / max(1, st["igemm_launches"]) / 1e6, 2),
             "algorithmic_gflop_per_launch": round(tot / max(1, st["igemm_launches"]) / 1e9, 2),
@@ -349,14 +362,39 @@ def main():
     roofline = None
     if rank == 0 and not args.no_profile_pass:
         roofline = profile_pass(headline, args.precision)
-        log(f"roofline ({args.precision}): {roofline['achieved']} of {roofline['peak']} TFLOP/s")
+        log(f"roofline ({args.precision}): {roofline['achieved']} of {roofline['peak']} TFLOP/s (MFMA issue: of {roofline['mfma_issue_peak']})")
+
+    # ---- ms/step as SURVEY.md 8(d) defines it: ONE UNet forward + sampler update (models/unet.py:865-895 + gaussian_diffusion.py:332-365) at
+    # batch B under the headline policy, through the step-wise API (`p_sample`), hipEvent-bracketed on the launch stream
+    unet_step = None
+    if rank == 0:
+        ti = steps // 2
+        xs = noise[1].contiguous()
+        nz = noise[2].contiguous()
+        tt = torch.full((B,), ti, device=dev, dtype=torch.long)
+        mk = {"lq": y}
+        if mask is not None:
+            mk["mask"] = mask
+        for _ in range(2):
+            diffusion.p_sample(model, xs, None, tt, clip_denoised=False, model_kwargs=mk, noise=nz)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        nrep = 10
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(nrep):
+            diffusion.p_sample(model, xs, None, tt, clip_denoised=False, model_kwargs=mk, noise=nz)
+        ev[1].record()
+        torch.cuda.synchronize()
+        unet_step = round(ev[0].elapsed_time(ev[1]) / nrep, 3)
+        log(f"ms_per_unet_step (one UNet forward + posterior update at batch {B}, t = {ti}): {unet_step}")
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference, fp32) on a bounded sample of the same workload; parity of the GPU
     # policies against it on (up to) all images of the batch
     cpu_baseline = parity = value_at_parity = value_fp16 = torch_baseline = None
+    torch_key = "torch_rocm_autocast_baseline"
     extra = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import resshift_oracle as oc  # checker / baseline only; never on the measured GPU path
+        from oracle import ref_baseline, resshift_oracle as oc  # checker / baseline only; never on the measured GPU path
 
         # use the cores this process may actually run on (cgroup/affinity aware), never more than torch's own default
         try:
@@ -366,7 +404,17 @@ def main():
         torch.set_num_threads(max(1, min(usable, torch.get_num_threads(), 64)))
         usd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         asd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
-        CH = 8                                        # images per oracle call: the TIMED sample is the first chunk
+        # the UNMODIFIED reference modules when they can be imported (oracle/_ref: the verified copy oracle/make_ref_copy.py ships to the GPU
+        # box), the oracle's restatement otherwise
+        reference = None
+        if ref_baseline.available() and not args.no_reference_modules:
+            try:
+                reference = ref_baseline.Reference(up, aep, dp, usd, asd)
+                log(f"cpu baseline runs the reference's own modules: {reference.source}")
+            except Exception as ex:   # a broken copy must not cost the bench line: fall back to the port and say so
+                log(f"reference modules unusable ({type(ex).__name__}: {ex}); cpu baseline falls back to the oracle port")
+                reference = None
+        CH = 8                                        # images per CPU call: the TIMED sample is the first chunk
         want = max(1, min(args.parity_images, B))
         refs, zrefs, irefs, cpu_first_s, cpu_total_s, nb = [], [], [], None, 0.0, 0
         log(f"cpu baseline: oracle on {torch.get_num_threads()} threads, chunks of {CH} images, up to {want} images / {args.cpu_seconds:.0f} s")
@@ -377,8 +425,13 @@ def main():
                 break
             sl = slice(nb, nb + n1)
             t0 = time.perf_counter()
-            r_img, r_aux = oc.sample_loop(usd, up, asd, aep, dp, y[sl].cpu(), [noise[k, sl].cpu() for k in range(steps + 1)],
-                                          mask=mask[sl].cpu() if mask is not None else None, return_aux=True)
+            if reference is not None:
+                r_img, r_z, r_idx = reference.sample(y[sl].cpu(), [noise[k, sl].cpu() for k in range(steps + 1)],
+                                                     mask=mask[sl].cpu() if mask is not None else None)
+                r_aux = {"z_final": r_z, "indices": r_idx}
+            else:
+                r_img, r_aux = oc.sample_loop(usd, up, asd, aep, dp, y[sl].cpu(), [noise[k, sl].cpu() for k in range(steps + 1)],
+                                              mask=mask[sl].cpu() if mask is not None else None, return_aux=True)
             dt = time.perf_counter() - t0
             if cpu_first_s is None:
                 cpu_first_s, first_n = dt, n1
@@ -396,7 +449,7 @@ def main():
             z = z[:nb].float().cpu()
             same = (idx.reshape(-1)[: nb * hw].cpu().long().reshape(nb, hw) == iref)
             per_img = [psnr_db(img[i], ref[i].clamp(-1, 1), 2.0) for i in range(nb)]
-            return {"policy": name, "images": nb,
+            return {"policy": name, "images": nb, "checker": "reference modules (CPU fp32)" if reference is not None else "oracle port (CPU fp32)",
                     "image_psnr_db": round(psnr_db(img, ref.clamp(-1, 1), 2.0), 1), "image_psnr_db_worst_image": round(min(per_img), 1),
                     "latent_psnr_db": round(psnr_db(z, zr, zp2p), 1),
                     "vq_code_agreement": round(same.float().mean().item(), 5),
@@ -424,12 +477,15 @@ def main():
                        "cores": rj.get("cores"), "cpu": rj.get("cpu"), "torch": rj.get("torch"),
                        "images_per_sec_by_batch": {str(r["batch"]): r["reference_images_per_sec"] for r in rj.get("rows", [])},
                        "oracle_over_reference_speed_same_host": {str(r["batch"]): r["oracle_over_reference"] for r in rj.get("rows", [])}}
-        cpu_baseline = {"value": round(first_n / cpu_first_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-                        "what": "oracle/ (functional restatement of the reference on torch CPU ops, fp32; faster than the reference modules' own loop on the "
-                                "same host by the factor in reference_modules.oracle_over_reference_speed_same_host, so GPU/CPU ratios are understated)",
-                        "sample": f"{first_n} images (the first chunk; the oracle then ran {nb - first_n} more, untimed for the baseline, for the parity check), same "
+        cpu_baseline = {"value": round(first_n / cpu_first_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+                        "kind": "reference" if reference is not None else "port",
+                        "what": (f"the reference's own modules, unmodified ({reference.source}): models.unet.UNetModelSwin + ldm.models.autoencoder.VQModelTorch driven by "
+                                 "GaussianDiffusion.p_sample_loop_progressive + decode_first_stage, CPU fp32, timed by THIS run on this host") if reference is not None else
+                                "oracle/ (functional restatement of the reference on torch CPU ops, fp32; oracle/_ref was not shipped, so the reference's own "
+                                "modules could not be timed here: see reference_modules for their build-container number)",
+                        "sample": f"{first_n} images (the first chunk; {nb - first_n} more ran untimed for the baseline, for the parity check), same "
                                   f"weights/inputs/noise as the first images of the GPU batch, full {steps}-step loop incl. VQ encode/decode",
-                        "seconds": round(cpu_first_s, 2), "oracle_seconds_total": round(cpu_total_s, 1), "reference_modules": ref_mod,
+                        "seconds": round(cpu_first_s, 2), "cpu_seconds_total": round(cpu_total_s, 1), "reference_modules": ref_mod,
                         "gpu_vs_cpu_psnr_db": hp["image_psnr_db"], "gpu_vs_cpu_psnr_db_worst_image": hp["image_psnr_db_worst_image"],
                         "gpu_vs_cpu_vq_code_agreement": hp["vq_code_agreement"], "gpu_vs_cpu_images": nb, "gpu_policy": args.precision,
                         "gpu_over_cpu": round(value / (first_n / cpu_first_s), 1)}
@@ -481,39 +537,51 @@ def main():
             ms32 = timed(p32, 1)
             par32.update({"ms_per_step": round(ms32, 2), "images_per_sec": round(B / ms32 * 1e3, 2), "steps_timed": 1})
             parity.append(par32)
-        # the restatement of the reference executed by stock PyTorch-ROCm ops (MIOpen / hipBLASLt) on this GPU under
-        # torch.autocast, as sampler.py:185 runs the reference, at the bench batch - its throughput (second call: MIOpen's find step is in
-        # the first) and ITS distance from the fp32 CPU path.  The unmodified modules themselves cannot run here (no reference tree on the
-        # GPU box); the oracle is pinned to them bit for bit on the CPU (tests/test_oracle.py).
+        # the reference run by stock PyTorch-ROCm ops (MIOpen / hipBLASLt) on this GPU under torch.autocast(float16), as
+        # sampler.py:185 runs it, at the bench batch - its throughput (second call: MIOpen's find step is in the first) and ITS distance from
+        # the fp32 CPU path.  The UNMODIFIED modules when oracle/_ref travelled (key `torch_rocm_autocast_baseline`), the oracle's
+        # restatement of them otherwise (key `torch_rocm_autocast_restatement_baseline`).
         if not args.no_torch_baseline:
+            ng = [noise[k] for k in range(steps + 1)]
             try:
-                usd_g = {k: v.to(dev) for k, v in usd.items()}
-                asd_g = {k: v.to(dev) for k, v in asd.items()}
-                ng = [noise[k] for k in range(steps + 1)]
+                if reference is not None:
+                    reference.to(dev)
 
-                def torch_run():
-                    with torch.autocast("cuda", dtype=torch.float16):
-                        return oc.sample_loop(usd_g, up, asd_g, aep, dp, y, ng, mask=mask, return_aux=True)
+                    def torch_run():
+                        return reference.sample(y, ng, mask=mask, autocast_dtype=torch.float16)
+                else:
+                    usd_g = {k: v.to(dev) for k, v in usd.items()}
+                    asd_g = {k: v.to(dev) for k, v in asd.items()}
+
+                    def torch_run():
+                        with torch.autocast("cuda", dtype=torch.float16):
+                            o, a = oc.sample_loop(usd_g, up, asd_g, aep, dp, y, ng, mask=mask, return_aux=True)
+                        return o, a["z_final"], a["indices"]
 
                 t0 = time.perf_counter()
                 torch_run()
                 torch.cuda.synchronize()
                 first_s = time.perf_counter() - t0
                 t0 = time.perf_counter()
-                o_t, aux_t = torch_run()
+                o_t, z_t, i_t = torch_run()
                 torch.cuda.synchronize()
                 t_s = time.perf_counter() - t0
-                tb = parity_of("torch autocast(fp16)", o_t, aux_t["z_final"], aux_t["indices"])
+                tb = parity_of("torch autocast(fp16)", o_t, z_t, i_t)
                 torch_baseline = {"value": round(B / t_s, 2), "unit": "images/sec", "batch": B, "seconds": round(t_s, 3),
-                                  "first_call_seconds": round(first_s, 2),
-                                  "what": "oracle/ RESTATEMENT of the reference (not the unmodified modules) on PyTorch-ROCm CUDA ops under torch.autocast(float16), "
-                                          "eager, batch = the bench batch, second call (MIOpen find-db warm)",
+                                  "first_call_seconds": round(first_s, 2), "kind": "reference" if reference is not None else "restatement",
+                                  "what": (f"the reference's own modules, unmodified ({reference.source}), moved to this GPU and run under torch.autocast(float16) "
+                                           "as sampler.py:185 does" if reference is not None else
+                                           "oracle/ RESTATEMENT of the reference (not the unmodified modules: oracle/_ref was not shipped) on PyTorch-ROCm ops under "
+                                           "torch.autocast(float16)") + ", eager, batch = the bench batch, second call (MIOpen find-db warm)",
                                   "parity_vs_cpu_fp32": tb, "engine_over_torch": round(value / (B / t_s), 1)}
                 log(f"torch autocast baseline: {torch_baseline}")
-                del usd_g, asd_g, o_t, aux_t
+                del o_t, z_t, i_t
+                if reference is not None:
+                    reference.to("cpu")
                 torch.cuda.empty_cache()
             except Exception as ex:  # the baseline is informational: never fail the bench line over it
                 torch_baseline = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            torch_key = "torch_rocm_autocast_baseline" if reference is not None else "torch_rocm_autocast_restatement_baseline"
 
     if rank == 0:
         dtypes = sorted(set(pu) | {pe, pd})
@@ -521,7 +589,9 @@ def main():
         line = {
             "metric": f"images/sec ({cdesc.split(',')[0]}, {steps}-step ResShift sampling loop incl. VQ encode/decode)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "ms_per_diffusion_step": round(ms_per_step / steps, 3),
+            "ms_per_step": round(ms_per_step, 3), "ms_per_diffusion_step": round(ms_per_step / steps, 3), "ms_per_unet_step": unet_step,
+            "ms_per_unet_step_note": f"SURVEY.md 8(d)'s ms/step: ONE UNet forward + sampler update at batch {B} under the headline policy (step-wise API, "
+                                     "hipEvents on the launch stream); ms_per_step is one whole pass of the path over a batch, ms_per_diffusion_step that / steps (autoencoder smeared in)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": names.get(dtypes[0], dtypes[0]) if len(dtypes) == 1 else
                      f"f16x2 encoder + UNet (hi+lo fp16 pairs, 3 MFMAs per product: fp32-class) + f16 decoder ({args.precision} policy)" if args.precision == PARITY_POLICY
@@ -539,7 +609,7 @@ def main():
                       "weight_broadcast_ms": round(1e3 * float(getattr(eng, "broadcast_s", 0.0)), 3)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_cpu_oracle": parity,
             "value_at_parity": value_at_parity, "value_fp16_unqualified": value_fp16, "other_policy_all_ranks": other_policy_all_ranks,
-            "torch_rocm_autocast_restatement_baseline": torch_baseline,
+            torch_key: torch_baseline,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

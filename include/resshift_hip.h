@@ -227,6 +227,11 @@ int rs_op_swin_mlp(const void* x, const void* w1_dev, const float* b1_dev, const
 /* the same on split storage (RS_PREC_SPLIT tensors of (hi, lo) fp16 pairs): weights packed [rows][K hi | K lo] fp16 on the device */
 int rs_op_swin_mlp_split(const void* x, const void* w1_dev, const float* b1_dev, const void* w2_dev, const float* b2_dev, const void* res, void* y,
                          int M, int E, int HD, void* stream);
+/* the last Swin block of a BasicLayer + its patch_unembed (models/swin_transformer.py:279,515,521-528) in one launch, split storage:
+ * y[M][NO] = Wu (x + fc2(GELU(fc1(x a + d))) + b2) + bu with the GroupNorm affine (a, d) = xcoef_dev [M / HW][2][E]; w2cat_dev = the product
+ * matrix [NO][HD + E] = [Wu W2 | Wu] packed [rows][K hi | K lo], bcat_dev = Wu b2 + bu; E = 192, HD = 768, NO = 160, HW % 128 == 0 */
+int rs_op_swin_mlp_split_unembed(const void* x, const float* xcoef_dev, const void* w1_dev, const float* b1_dev, const void* w2cat_dev, const float* bcat_dev,
+                                 void* y, int M, int HW, int E, int HD, int NO, void* stream);
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream);
 int rs_op_vq(const float* z, const float* codebook_dev, float* zq, int32_t* idx, long long N, int NE, int D, void* stream);
 int rs_op_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int out_prec, void* stream);

@@ -1,9 +1,10 @@
-"""ORACLE support — only usable where /root/reference exists (the build container).
+"""ORACLE support — imports the UNMODIFIED reference modules so that oracle/make_golden.py and tests/test_oracle.py can pin
+the restatement in resshift_oracle.py against the real thing, and so that bench.py's baseline legs can time the reference itself.
 
-Imports the UNMODIFIED reference modules so that oracle/make_golden.py and tests/test_oracle.py can pin
-the restatement in resshift_oracle.py against the real thing.  The reference needs `timm` for three
-init helpers (models/swin_transformer.py:13); a stub package providing them is injected.
-Nothing on the GPU box may import this module.
+Where the modules come from, in this order: $RESSHIFT_REFERENCE, /root/reference (the build container), oracle/_ref/ (the byte-identical,
+git-ignored copy oracle/make_ref_copy.py makes of the hot-path modules; it is what exists on the GPU box - its sha256 manifest is
+verified before anything is imported from it).  The reference needs `timm` for three init helpers (models/swin_transformer.py:13); a stub
+package providing them is injected.  Test / measurement infrastructure: nothing under resshift_amd/ imports this module.
 """
 from __future__ import annotations
 
@@ -11,19 +12,56 @@ import os
 import sys
 import types
 
-REF = os.environ.get("RESSHIFT_REFERENCE", "/root/reference")
+COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _copy_ok() -> bool:
+    """oracle/_ref exists and every file matches the manifest make_ref_copy.py wrote (an edited copy is not "the reference")"""
+    import hashlib
+    import json
+
+    mpath = os.path.join(COPY, "MANIFEST.json")
+    if not os.path.exists(mpath):
+        return False
+    try:
+        with open(mpath) as fh:
+            man = json.load(fh)["sha256"]
+        for rel, dig in man.items():
+            with open(os.path.join(COPY, rel), "rb") as fh:
+                if hashlib.sha256(fh.read()).hexdigest() != dig:
+                    return False
+    except (OSError, KeyError, ValueError):
+        return False
+    return "models/unet.py" in man
+
+
+def where() -> "str | None":
+    """directory the reference modules would be imported from, or None"""
+    for cand in (os.environ.get("RESSHIFT_REFERENCE"), "/root/reference"):
+        if cand and os.path.isdir(os.path.join(cand, "models")):
+            return cand
+    return COPY if _copy_ok() else None
+
+
+REF = where() or "/root/reference"
 
 
 def available() -> bool:
-    return os.path.isdir(os.path.join(REF, "models"))
+    return where() is not None
 
 
-def load():
-    """returns (UNetModelSwin, VQModelTorch, create_gaussian_diffusion) from the reference tree."""
+def is_copy() -> bool:
+    return where() == COPY
+
+
+def load(prefer: "str | None" = None):
+    """returns (UNetModelSwin, VQModelTorch, create_gaussian_diffusion) from the reference tree (or its verified copy)."""
     import torch
 
-    if not available():
-        raise RuntimeError("reference tree not present")
+    global REF
+    REF = prefer or where()
+    if REF is None:
+        raise RuntimeError("reference modules not present (neither /root/reference nor a verified oracle/_ref copy)")
     if "timm" not in sys.modules:
         timm = types.ModuleType("timm")
         models = types.ModuleType("timm.models")

@@ -111,6 +111,7 @@ SIGNATURES = {
     "rs_op_ae_flash_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rs_op_ae_flash_attention_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rs_op_swin_mlp_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rs_op_swin_mlp_split_unembed": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rs_op_softmax_rows": (_I, [_P, _P, _LL, _I, _I, _P]),
     "rs_op_vq": (_I, [_P, _P, _P, _P, _LL, _I, _I, _P]),
     "rs_op_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -60,6 +60,10 @@ int rs_ae_flash_split_launch(const void* q, int ldq, const void* k, int ldk, con
 int rs_swin_mlp_supported(int E, int HD);
 int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                              int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, const GNTail* tail, hipStream_t st);
+int rs_swin_mlp_split_launch_n(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
+                               int ldres, int ldy, int E, int HD, int NO, const float* xcoef, int HW, float* ystats, int ystats_ld, const GNTail* tail,
+                               hipStream_t st);
+int rs_swin_mlp_split_unembed_supported(int E, int HD, int NO);
 int rs_swin_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                        int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld, hipStream_t st);
 int rs_small_linear_launch(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int silu_in, int silu_out, hipStream_t st);
@@ -162,7 +166,8 @@ struct ConvW {
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResBlockW { GNW n1, n2; ConvW c1, c2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int film_off = -1; ConvW emb; };
 struct SwinBlockW { GNW n1, n2; ConvW qkv, proj, fc1, fc2; float* bias_t = nullptr; float* bias_n = nullptr; int shift = 0; };
-struct BasicLayerW { ConvW embed, unembed; std::vector<SwinBlockW> blocks; int C = 0, E = 0; };
+struct BasicLayerW { ConvW embed, unembed; std::vector<SwinBlockW> blocks; int C = 0, E = 0;
+                     ConvW unfold; bool has_unfold = false; };   // unfold: [Wu W2 | Wu] of the last block's fc2 and patch_unembed (basiclayer())
 struct UBlock {
     bool has_conv = false, has_res = false, has_swin = false, has_down = false, has_up = false;
     ConvW conv; ResBlockW res; BasicLayerW swin; int out_ch = 0; int level = 0;
@@ -352,11 +357,13 @@ struct Exec {
     // the fused Swin MLP belongs to the same MFMA family for the roofline bookkeeping: both GEMMs' FLOPs, compulsory bytes
     void swin_mlp(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y, int M, int ldx,
                   int ldres, int ldy, int E, int HD, const float* xcoef = nullptr, int HW = 0, int dt = RS_F16, float* ystats = nullptr,
-                  int ystats_ld = 0, const GNTail* tail = nullptr) {
+                  int ystats_ld = 0, const GNTail* tail = nullptr, int NO = 0) {
         const int sp = dt == RS_F16S;
-        igemm_flops[sp ? 2 : 0] += 2.0 * 2.0 * (double)M * (double)E * (double)HD;
-        fam_note(sp ? F_SWINMLP_S : F_SWINMLP, 2.0 * 2.0 * (double)M * (double)E * (double)HD, M, E, HD);
-        igemm_bytes += (sp ? 4.0 : 2.0) * ((double)M * E * (res ? 3.0 : 2.0) + 2.0 * (double)E * HD);
+        if (NO <= 0) NO = E;   // (NO != E: patch_unembed folded in - fc1, then the product matrix over [h ; x])
+        const double fl = 2.0 * (double)M * ((double)E * HD + (double)NO * (NO != E ? HD + E : HD));
+        igemm_flops[sp ? 2 : 0] += fl;
+        fam_note(sp ? F_SWINMLP_S : F_SWINMLP, fl, M, NO, HD);
+        igemm_bytes += (sp ? 4.0 : 2.0) * ((double)M * (E * ((res || NO != E) ? 2.0 : 1.0) + NO) + (double)E * HD + (double)NO * (NO != E ? HD + E : HD));
         ++igemm_launches;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && prof->on) {
@@ -368,7 +375,7 @@ struct Exec {
             e0 = prof->ev[prof->used++]; e1 = prof->ev[prof->used++];
             (void)hipEventRecord(e0, st);
         }
-        if (sp) check(rs_swin_mlp_split_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, ystats, ystats_ld, tail, st), "swin_mlp_split");
+        if (sp) check(rs_swin_mlp_split_launch_n(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, NO, xcoef, HW, ystats, ystats_ld, tail, st), "swin_mlp_split");
         else check(rs_swin_mlp_launch(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, xcoef, HW, ystats, ystats_ld, st), "swin_mlp");
         if (e1) (void)hipEventRecord(e1, st);
     }
@@ -436,8 +443,17 @@ struct rs_engine {
     float* codebook = nullptr;
 
     // ---------------------------------------------------------------- build
+    // tensors the packer derives from checkpoint tensors (products of two linear maps that run as one GEMM): made on first use
+    std::map<std::string, std::function<bool(HostTensor&)>> derived;
     const HostTensor* find(const std::string& k) {
         auto it = host.find(k);
+        if (it == host.end()) {
+            auto d = derived.find(k);
+            if (d != derived.end()) {
+                HostTensor t;
+                if (d->second(t)) it = host.emplace(k, std::move(t)).first;
+            }
+        }
         if (it == host.end()) { if (build_err.empty()) build_err = "missing state_dict key: " + k; return nullptr; }
         return &it->second;
     }
@@ -621,6 +637,43 @@ struct rs_engine {
             b.blocks.push_back(s);
         }
         b.unembed = add_conv(p + ".patch_unembed.proj", E, C, 1, 1);
+        // patch_unembed folded into the last block's fused split MLP (swin_mlp.hip, NO != E): y = Wu (x + W2 h + b2) + bu
+        //   = [Wu W2 | Wu] [h ; x] + (Wu b2 + bu) - a [C][hidden + E] matrix and a C-vector, products in double from the checkpoint's tensors
+        if (cfg.enable_split && u.swin_depth > 0 && rs_swin_mlp_split_unembed_supported(E, hidden, C)) {
+            const std::string fk = p + ".patch_unembed.fold", uk = p + ".patch_unembed.proj", mk = p + ".blocks." + std::to_string(u.swin_depth - 1) + ".mlp.fc2";
+            derived[fk + ".weight"] = [this, uk, mk, E, hidden, C](HostTensor& t) {
+                const HostTensor* wu = find(uk + ".weight"); const HostTensor* w2 = find(mk + ".weight");
+                if (!wu || !w2 || wu->data.size() != (size_t)C * E || w2->data.size() != (size_t)E * hidden) return false;
+                t.data.assign((size_t)C * (hidden + E), 0.f);
+                t.shape = {C, hidden + E, 1, 1};
+                std::vector<double> row(hidden);
+                for (int n = 0; n < C; ++n) {
+                    std::fill(row.begin(), row.end(), 0.0);
+                    for (int e = 0; e < E; ++e) {
+                        const double a = wu->data[(size_t)n * E + e];
+                        const float* w2r = w2->data.data() + (size_t)e * hidden;
+                        for (int h = 0; h < hidden; ++h) row[h] += a * (double)w2r[h];
+                    }
+                    float* o = t.data.data() + (size_t)n * (hidden + E);
+                    for (int h = 0; h < hidden; ++h) o[h] = (float)row[h];
+                    for (int e = 0; e < E; ++e) o[hidden + e] = wu->data[(size_t)n * E + e];
+                }
+                return true;
+            };
+            derived[fk + ".bias"] = [this, uk, mk, E, C](HostTensor& t) {
+                const HostTensor* wu = find(uk + ".weight"); const HostTensor* bu = find(uk + ".bias"); const HostTensor* b2 = find(mk + ".bias");
+                if (!wu || !bu || !b2 || wu->data.size() != (size_t)C * E || bu->data.size() != (size_t)C || b2->data.size() != (size_t)E) return false;
+                t.data.resize(C); t.shape = {C};
+                for (int n = 0; n < C; ++n) {
+                    double a = bu->data[n];
+                    for (int e = 0; e < E; ++e) a += (double)wu->data[(size_t)n * E + e] * (double)b2->data[e];
+                    t.data[n] = (float)a;
+                }
+                return true;
+            };
+            b.unfold = add_conv(fk, hidden + E, C, 1, 1);
+            b.has_unfold = true;
+        }
         return b;
     }
     bool in_attn_res(int ds) const {
@@ -861,7 +914,7 @@ struct rs_engine {
             p.no_halo = (x.dt == RS_F16S && big(w)) ? 1 : 0;   // (the launcher picks the kernel from the parameter block: tell it what halo_conv() decided)
             p.splitk = splitk; p.partial = partial;
             p.xcoef = xcoef; p.xact = xact;
-            if (skw) { p.sx = skx->p; p.sw = skw->ws; p.sbias = skw->bias; p.sC = skx->C; p.sld = skx->ld; }   // folded 1x1 shortcut (skip_fold())
+            if (skw) { p.sx = skx->p; p.sw = skw->w_for(x.dt); p.sbias = skw->bias; p.sC = skx->C; p.sld = skx->ld; }   // folded 1x1 shortcut (skip_fold())
             if (y.st) {   // statistics for the consuming GroupNorm: the halo kernel's or the generic split kernel's epilogue (or their split-K reduce)
                 const bool halo = !x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res);
                 if (halo || (!x1 && x.dt == RS_F16S && y.dt == RS_F16S)) { p.ystats = y.st; p.ystats_ld = y.stld; }
@@ -887,8 +940,10 @@ struct rs_engine {
     bool skip_fold(const Exec& ex, const ResBlockW& r, const View& X, const View& h1, const View& Y) const {
         static const bool on = []() { const char* e = getenv("RS_SKIP_FOLD"); return !(e && e[0] == '0'); }();
         static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
-        if (!on || !fold || ex.dbg || !r.has_skip || X.dt != RS_F16S || Y.dt != RS_F16S || big(r.skip) || big(r.c2)) return false;
-        if (!r.skip.ws || r.skip.KH != 1 || X.C != r.skip.CinP || (X.C % 32) || (X.ld % 8) || X.H != Y.H || X.W != Y.W) return false;
+        static const bool on16 = []() { const char* e = getenv("RS_SKIP_FOLD_F16"); return !(e && e[0] == '0'); }();   // (fp16 storage: the decoder's nin_shortcuts, the fp16 policy's UNet)
+        if (!on || !fold || ex.dbg || !r.has_skip || (X.dt != RS_F16S && !(X.dt == RS_F16 && on16)) || Y.dt != X.dt) return false;
+        if (X.dt == RS_F16S && (big(r.skip) || big(r.c2))) return false;
+        if (!r.skip.w_for(X.dt) || r.skip.KH != 1 || X.C != r.skip.CinP || (X.C % 32) || (X.ld % 8) || X.H != Y.H || X.W != Y.W) return false;
         int sk = 1, seg = 0;
         return halo_conv(r.c2, h1, Y, nullptr, &sk, &seg) && sk == 1 && seg == 0;
     }
@@ -1141,6 +1196,27 @@ struct rs_engine {
             const float* coef2 = nullptr;
             if (fold2) coef2 = gn_coef(ex, s.n2, e2, 1e-5f, nullptr);
             else { n2 = ex.T(X.B, X.H, X.W, E, X.dt); gn(ex, s.n2, e2, n2, 1e-5f, RS_ACT_NONE); }
+            // patch_unembed inside the last block's MLP launch (swin_mlp.hip, NO != E): split storage, norm2 folded (the kernel's x is the block's
+            // raw input = its shortcut), the product matrix below the scaled-fragment limit.  RS_UNEMBED_FOLD=0: the 1x1 conv as a launch.
+            static const bool unfold_on = []() { const char* v = getenv("RS_UNEMBED_FOLD"); return !(v && v[0] == '0'); }();
+            const bool unfold = unfold_on && fuse_mlp && fold2 && X.dt == RS_F16S && &s == &b.blocks.back() && b.has_unfold && b.unfold.ws &&
+                                !big(b.unfold) && Y.dt == RS_F16S && Y.C == b.C && rs_swin_mlp_split_unembed_supported(E, s.fc1.Cout, b.C);
+            if (unfold) {
+                Y.st = nullptr; Y.st2 = nullptr; Y.st_prod = -1;
+                if (out_stats && sstats && HWt % 128 == 0 && Mtok % 128 == 0) {   // statistics (+ tail) for the GroupNorm that consumes the layer's output
+                    Y.stS = HWt / 128; Y.stld = Y.C;
+                    Y.st = ex.pool((size_t)X.B * Y.stS * Y.stld * 2 * sizeof(float));
+                    Y.st_prod = ex.prod_seq++;
+                }
+                if (!ex.dry) {
+                    GNTail tl{};
+                    const GNTail* tlp = (Y.st && ex.fill_tail(Y.st_prod, X.B, tl)) ? &tl : nullptr;
+                    ex.swin_mlp(e2.p, s.fc1.w_for(X.dt), s.fc1.bias, b.unfold.ws, b.unfold.bias, nullptr, Y.p, Mtok, e2.ld, 0, Y.ld, E, s.fc1.Cout, coef2, HWt,
+                                X.dt, Y.st, Y.stld, tlp, b.C);
+                }
+                ex.reset(mk);
+                return;
+            }
             if (fuse_mlp) {
                 e3 = ex.T(X.B, X.H, X.W, E, X.dt);
                 const bool is_last = &s == &b.blocks.back();   // (the last block's output feeds patch_unembed, not a GroupNorm)
@@ -2193,6 +2269,13 @@ int rs_op_swin_mlp_split(const void* x, const void* w1_dev, const float* b1_dev,
                          int M, int E, int HD, void* stream) {
     const int rc = rs_swin_mlp_split_launch(x, w1_dev, b1_dev, w2_dev, b2_dev, res, y, M, E, E, E, E, HD, nullptr, 0, nullptr, 0, nullptr, (hipStream_t)stream);
     if (rc) fail("swin_mlp_split launch rejected the shape (split storage, E = 192, HD = 768 only)");
+    return rc;
+}
+int rs_op_swin_mlp_split_unembed(const void* x, const float* xcoef_dev, const void* w1_dev, const float* b1_dev, const void* w2cat_dev, const float* bcat_dev,
+                                 void* y, int M, int HW, int E, int HD, int NO, void* stream) {
+    const int rc = rs_swin_mlp_split_launch_n(x, w1_dev, b1_dev, w2cat_dev, bcat_dev, nullptr, y, M, E, 0, NO, E, HD, NO, xcoef_dev, HW, nullptr, 0, nullptr,
+                                              (hipStream_t)stream);
+    if (rc) fail("swin_mlp_split (+ patch_unembed) launch rejected the shape (split storage, E = 192, HD = 768, NO = 160, HW % 128 == 0 only)");
     return rc;
 }
 int rs_op_softmax_rows(const float* s, void* out, long long nrows, int ncols, int out_prec, void* stream) {

@@ -8,14 +8,16 @@ namespace {
 
 template <bool SPLIT>
 hipError_t launch4_t(const IGemmParams& p, int TW, int BC, hipStream_t st) {
-    if (TW == 64) return BC == 160 ? launch4_cfg<64, 160, SPLIT>(p, st) : (BC == 192 ? launch4_cfg<64, 192, SPLIT>(p, st) : launch4_cfg<64, 128, SPLIT>(p, st));
-    return BC == 160 ? launch4_cfg<32, 160, SPLIT>(p, st) : (BC == 192 ? launch4_cfg<32, 192, SPLIT>(p, st) : launch4_cfg<32, 128, SPLIT>(p, st));
+    if constexpr (!SPLIT) {   // (split storage never plans the 192-channel tile - over the register budget, rs_igemm4_plan - so it is not instantiated)
+        if (BC == 192) return TW == 64 ? launch4_cfg<64, 192, false>(p, st) : launch4_cfg<32, 192, false>(p, st);
+    } else if (BC == 192) return hipErrorInvalidValue;
+    if (TW == 64) return BC == 160 ? launch4_cfg<64, 160, SPLIT>(p, st) : launch4_cfg<64, 128, SPLIT>(p, st);
+    return BC == 160 ? launch4_cfg<32, 160, SPLIT>(p, st) : launch4_cfg<32, 128, SPLIT>(p, st);
 }
 
 }  // namespace
 
 extern "C" int rs_igemm4_seg_launch(const IGemmParams* pp, int in_dt, int SEG, int BC, hipStream_t st);   // igemm4s.hip
-extern "C" int rs_igemm4_w4_launch(const IGemmParams* pp, int in_dt, int BC, hipStream_t st);              // igemm4w.hip
 extern "C" int rs_splitk_reduce_launch(const IGemmParams* p, int out_dt, hipStream_t st);                  // igemm.hip
 
 namespace {
@@ -118,10 +120,8 @@ extern "C" int rs_splitk_reduce_stats_launch(const IGemmParams* p, int out_dt, h
 // the small planes of the 16 x 16 / 8 x 8 UNet levels (SEG = 16: one 16 x 16 image per tile; SEG = 8: four 8 x 8 images per tile, batch
 // a multiple of 4) with split-K over stages chosen so that tiles x slices fill the chip once (SK).  RS_IGEMM_V4=0 disables the kernel
 // (1: fp16 only, 2: split only); RS_IGEMM_V4_SEG=0 keeps the small planes on the generic kernels (A/B runs).
-// *SEG carries the tile variant: 0 = 256-pixel tiles on 8 waves, 8 / 16 = the small-plane geometries, -4 = 128-pixel tiles (4 x 32) on 4
-// waves, two workgroups per CU (RS_IGEMM_V4_W4: bit 0 fp16, bit 1 split storage).
+// *SEG carries the tile variant: 0 = 256-pixel tiles on 8 waves, 8 / 16 = the small-plane geometries.
 extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC, int* SEG, int* SK) {
-    static const int w4_on = []() { const char* e = getenv("RS_IGEMM_V4_W4"); return e ? atoi(e) : 0; }();
     static const int on = []() { const char* e = getenv("RS_IGEMM_V4"); return e ? atoi(e) : 3; }();
     // bit 0: fp16, bit 1: split storage, bit 2: the 16 x 16 planes as well.  Default 2 = the 8 x 8 planes in split storage - measured
     // (profiles/r3_small_planes.txt, us per launch at batch 32, generic kernel -> halo kernel): split 8 x 8, 640 -> 640: 96 -> 62, 1280 ->
@@ -164,11 +164,6 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
         return 1;
     }
     if (waste(192) < bw) { best = 192; bw = waste(192); }
-    if (((in_dt == RS_F16 && (w4_on & 1)) || (in_dt == RS_F16S && (w4_on & 2))) && (p.Wo % 32 == 0) && (p.Ho % 4 == 0) && p.Cout >= 96 &&
-        best != 192) {   // (BC = 192 on four waves does not fit 256 VGPRs)
-        const long long tiles4 = (long long)p.B * (p.Ho / 4) * (p.Wo / 32) * ((p.Cout + best - 1) / best);
-        if (tiles4 >= 2 * min_tiles) { *TW = 32; *BC = best; *SEG = -4; *SK = 1; return 1; }
-    }
     // 4 x 64 tiles on planes that allow them, except for the 160-channel tile: 8 x 32 leaves room for the third weight slot
     int tw = (p.Wo % 64 == 0) ? 64 : 32;
     if (best == 160 && (p.Wo % 32 == 0) && (p.Ho % 8 == 0)) tw = 32;
@@ -201,8 +196,7 @@ extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC
     if (sk > 1) { p.ystats = nullptr; p.tail.coef = nullptr; }   // slices cannot see the final values: the reduce kernel produces the statistics (and carries the tail)
     if (seg == 8 && want_stats && sk == 1) return -2;   // four images per tile: no per-image statistics from the tile epilogue
     int rc;
-    if (seg == -4) rc = rs_igemm4_w4_launch(&p, in_dt, BC, st);
-    else if (seg) rc = rs_igemm4_seg_launch(&p, in_dt, seg, BC, st);
+    if (seg) rc = rs_igemm4_seg_launch(&p, in_dt, seg, BC, st);
     else rc = (in_dt == RS_F16S ? launch4_t<true>(p, TW, BC, st) : launch4_t<false>(p, TW, BC, st)) == hipSuccess ? 0 : -1;
     if (rc != 0 || sk == 1) return rc;
     p.ystats = want_stats; p.tail = want_tail;
@@ -217,5 +211,5 @@ extern "C" int rs_igemm4_stats_px(const IGemmParams* pp, int in_dt) {
     const int HW = pp->Ho * pp->Wo;
     if (sk > 1) return (HW > 256 && (HW % 256)) ? 0 : std::min(HW, 256);
     if (seg == 8) return 0;
-    return seg == -4 ? 128 : 256;
+    return 256;
 }

@@ -65,18 +65,27 @@ __device__ long long g_ig4_clk[4 * 8192];   // per workgroup: cycle counter at k
 #endif
 // ABL (builds with -DRS_SPLIT_ABLATE only, RS_IGEMM4_ABL=n selects): timing ablations, results wrong: bit 0 = no weight loads
 // after the first two stages, bit 1 = no halo loads after chunk 0, bit 2 = no MFMAs
-// NWV = 4 (igemm4w.hip): 128-pixel tiles (4 x 32) on FOUR waves (2 pixel-waves x 2 channel-waves, the same 64 x BC/2 wave tile) with ONE halo
-// buffer and two (BC = 128: three) weight slots: <= 80 KB of LDS, so TWO workgroups share a CU.  A single workgroup of this shape is
-// slower than the 8-wave one (the next chunk's halo can only be requested once the current one has been read to the end: one exposed L2
-// round trip per chunk), but the other workgroup's MFMAs fill that gap, and - the point - its K loop runs while this one sits in its
-// prologue or in its HBM-bound epilogue (15 - 23 % of a split-storage tile, profiles/r3_igemm4_phases.txt).
+// (Round 3's NWV = 4 form - 128-pixel tiles on four waves, two workgroups per CU - measured within 1 % of this one on every shape
+// (profiles/r3_negative_results.txt) and left the tree in round 5, as did the GroupNorm pass riding on taps 7 / 8, profiles/r3_igemm4_early_gn.txt.)
+//
+// SCHED (round 5): where a stage's REFILL code sits.  The refill of a stage - one halo piece of the next chunk and the weight tile two
+// stages ahead: ~110 scalar / vector instructions of address arithmetic in front of four LDS-DMA instructions - used to run right behind
+// the stage's barrier in all eight waves at once, i.e. in BOTH waves of every SIMD, with the matrix pipe idle until the first fragments
+// had been read behind it (profiles/r3_igemm4_phases.txt: 3 016 cycles per split-storage stage for 1 920 cycles of MFMA issue).  With
+// SCHED = 1 every wave issues its fragment reads first; the waves 0 - 3 then refill and go on to their MFMAs, the waves 4 - 7 (the
+// other wave of each SIMD: a workgroup's waves go to the SIMDs in cyclic order) run the first SCH_AT channel fragments' MFMAs, refill,
+// and finish - whichever wave of a SIMD is in its address arithmetic, the other one keeps the matrix pipe fed.
 template <int TW, int BC, bool SPLIT, int SEG = 0, int ABL = 0, int NWV = 8>
 __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
-    static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16) && NWV == 8), "segmented tiles use the 8 x 32 geometry");
-    static_assert(NWV == 8 || NWV == 4, "8 waves (one workgroup per CU) or 4 waves (two per CU)");
+    static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16)), "segmented tiles use the 8 x 32 geometry");
+    static_assert(NWV == 8, "8 waves, one workgroup per CU");
     constexpr int NT = 64 * NWV, WPX = NWV / 2;   // threads; pixel-waves (x 2 channel-waves)
-    constexpr int NXB = NWV == 8 ? 2 : 1;         // halo buffers
-    constexpr int LDSCAP = NWV == 8 ? 160 * 1024 : 80 * 1024;
+    constexpr int NXB = 2;                        // halo buffers
+    constexpr int LDSCAP = 160 * 1024;
+#ifndef RS_IG4_SCHED
+#define RS_IG4_SCHED 1
+#endif
+    constexpr int SCHED = (ABL == 0) ? RS_IG4_SCHED : 0;
     constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
     // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
     // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
@@ -130,7 +139,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // makes the compiler park the whole struct in scratch memory, and scratch loads inside the K loop drain the DMA queue)
     const float* const xcoef = p.xcoef;
     const int xact = p.xact, Hs = p.Hs, Ws = p.Ws;
-    const bool early_on = !(p.dbg & 16);   // A/B knob (RS_IG4_EARLY_GN=0): the GroupNorm pass as a phase of its own
     // halo row hr of the tile -> source pixel (image index in `img`); false: zero padding / separator column / outside the image
     auto halo_src = [&](int hr, unsigned& pix, int& img) -> bool {
         const int hy = hr / HWD, hx = hr - hy * HWD;
@@ -158,11 +166,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     const int Cout = p.Cout, Ktot = p.Ktot, ld0 = p.ld0;
     // Folded 1x1 shortcut (IGemmParams::sx): chunks nch .. nch + nch2 - 1 of the halo sequence are 32-channel chunks of the RAW block
     // input, stages 9 nch .. 9 nch + nch2 - 1 their centre-tap weight tiles [Cout][sC hi | sC lo] - the shortcut's GEMM as nch2 more
-    // stages of this accumulator.  Only in the instantiations the engine asks for it (split storage, big planes, 8 waves).
-    constexpr bool SKIPOK = SPLIT && SEG == 0 && NWV == 8 && ABL == 0;
+    // stages of this accumulator (fp16 storage: 64-channel chunks, rows [Cout][sC]; the last chunk may be half full).  Only in the
+    // instantiations the engine asks for it (big planes, 8 waves).
+    constexpr bool SKIPOK = SEG == 0 && NWV == 8 && ABL == 0;
     const int nch = (Cin + KC - 1) / KC;
     const int sC = (SKIPOK && p.sx) ? p.sC : 0, sld = p.sld;
-    const int nch2 = sC / KC, ncht = nch + nch2;
+    const int nch2 = (sC + KC - 1) / KC, ncht = nch + nch2;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.sx, 0, p.sx_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.sw, 0, p.sw_bytes, 0x00020000);
     auto issue_x = [&](int c, int k) {   // piece k of chunk c -> halo buffer c & 1 (wave w owns pieces w, w + NWV, ...)
@@ -176,8 +185,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             const bool sk = c >= nch;
             const int cc = sk ? c - nch : c;
             const unsigned ldc = (unsigned)(sk ? sld : ld0), Cc = (unsigned)(sk ? sC : Cin);
-            const unsigned cb = (unsigned)(cc * 32 + (kcp & 3) * 8);
-            const unsigned off = pix * ldc * 4u + (kcp >> 2) * ldc * 2u + cb * 2u;
+            const unsigned cb = SPLIT ? (unsigned)(cc * 32 + (kcp & 3) * 8) : (unsigned)(cc * 64 + kcp * 8);
+            const unsigned off = SPLIT ? pix * ldc * 4u + (kcp >> 2) * ldc * 2u + cb * 2u : pix * ldc * 2u + cb * 2u;
             lds_dma16(sk ? rsx : rx, smem + (c & 1) * XBUF + (wave + NWV * k) * 1024, (inside && cb < Cc) ? off : INV);
             return;
         }
@@ -195,15 +204,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             const bool sk = s >= 9 * nch;
             const int c = sk ? nch + (s - 9 * nch) : s / 9, tap = sk ? 0 : s - c * 9;
             const unsigned Kc = (unsigned)(sk ? sC : Ktot), Cc = (unsigned)(sk ? sC : Cin);
-            const unsigned cb = (unsigned)((sk ? c - nch : c) * 32 + (kcp & 3) * 8);
-            const unsigned kb = (unsigned)tap * Cc * 2u + cb * 2u + (kcp >> 2) * Kc * 2u;
+            const unsigned cb = SPLIT ? (unsigned)((sk ? c - nch : c) * 32 + (kcp & 3) * 8) : (unsigned)((sk ? c - nch : c) * 64 + kcp * 8);
+            const unsigned kb = (unsigned)tap * Cc * 2u + cb * 2u + (SPLIT ? (kcp >> 2) * Kc * 2u : 0u);
             const __amdgpu_buffer_rsrc_t rc = sk ? rsw : rw;
 #pragma unroll
             for (int i = 0; i < RW; ++i) {
                 if (RWP && i == RW - 1 && !wpart) continue;
                 const int n = n0 + RR * i + rr;
                 const bool ok = RR * i + rr < BC && n < Cout && cb < Cc;
-                lds_dma16(rc, sbase + (RR * i) * 128, ok ? (unsigned)n * Kc * 4u + kb : INV);
+                lds_dma16(rc, sbase + (RR * i) * 128, ok ? (unsigned)n * Kc * (SPLIT ? 4u : 2u) + kb : INV);
             }
             return;
         }
@@ -336,20 +345,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             else apply(c, std::integral_constant<int, RS_ACT_NONE>{}, cf, k0_tag, k1_tag);
         }
     };
-    constexpr int NC_ALL = SPLIT ? NCELL_S : NCELL, NC_HALF = (NC_ALL + 1) / 2;
-    // EARLY (RS_IG4_EARLY_GN=1; default OFF - measured neutral, profiles/r3_igemm4_early_gn.txt; not for the four-image tiles): the GroupNorm pass of chunk c + 1 does not get a phase of its
-    // own in front of that chunk's first stage - both waves of every SIMD in VALU code, the matrix pipe idle for 13 - 25 % of a chunk -
-    // but rides on the MFMAs of taps 7 and 8 of chunk c: the halo pieces of chunk c + 1 were requested with taps 0 .. 6 and are complete
-    // behind tap 7's barrier, half of a thread's cells go with each of the two stages, and the barrier that opens chunk c + 1 orders
-    // the LDS writes against the fragment reads.
-    // (compiled in only with -DRS_IG4_EARLY_BUILD: the doubled stage body costs registers - fp16 BC = 160: 185 -> 256 VGPRs; BC = 192
-    // does not fit at all)
-#ifdef RS_IG4_EARLY_BUILD
-    constexpr bool EARLY = SEG != 8 && BC < 192 && NXB == 2 && !(ABL & 8);
-#else
-    constexpr bool EARLY = false;
-#endif
-    bool pre_applied = false;   // chunk c's halo was transformed during chunk c - 1
+    constexpr int NC_ALL = SPLIT ? NCELL_S : NCELL;
     const int nst = nch * 9 + nch2;   // (+ the shortcut's centre-tap stages)
     // One barrier per (chunk, tap) stage: weight tile s+1 and one piece of the next chunk's halo are requested right behind it
     // and have the whole stage (40 - 48 MFMAs per wave) to land.  (A variant with the barrier between the two k-steps and two
@@ -395,24 +391,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                 if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (EARLY && tap == 0 && pre_applied) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this thread's early GroupNorm writes
             __builtin_amdgcn_s_barrier();
             if (tap == t_first) {
-                if (NXB == 1 && c > c_beg) {
-                    // single halo buffer: every wave is behind chunk c - 1's last fragment reads (this stage's barrier), so chunk c is
-                    // requested only now - one exposed L2 round trip per chunk, covered by the other workgroup on this CU
-#pragma unroll
-                    for (int k = 0; k < XPW; ++k) issue_x(c, k);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                if (xcoef && !pre_applied) {
+                if (xcoef) {
                     apply_cells(c, load_coef(c), std::integral_constant<int, 0>{}, std::integral_constant<int, NC_ALL>{});
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
-                pre_applied = false;
-                if (NXB == 2 && c > c_beg) {   // the fragment offsets move over to the other halo buffer
+                if (c > c_beg) {   // the fragment offsets move over to the other halo buffer
                     const int flip = (c & 1) ? XBUF : -XBUF;
 #pragma unroll
                     for (int j = 0; j < FP; ++j)
@@ -420,42 +406,46 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                         for (int q = 0; q < 3; ++q) xfo[j][q] += flip;
                 }
             }
-            // early GroupNorm pass of chunk c + 1 (see EARLY): possible when its halo pieces went out with taps 0 .. 6 of this chunk
-            const bool early = EARLY && xcoef != nullptr && c < c_last && t_first == 0 && early_on;
-            Coef cf_next{};
-            if (tap >= 7 && early) cf_next = load_coef(c + 1);   // (in front of this stage's refills: its wait does not drain them)
             // refills: one piece of the next chunk's halo (buffer (c+1)&1: chunk c-1 is finished everywhere), then the next weight tile
             // (a slice that enters the chunk at tap t_first > 0 has 9 - t_first stages for the XPW pieces: the rest goes with tap 8)
-            if constexpr (SLICED) {
-                if (c < c_last && !(ABL & 2)) {
-                    const int k0 = tap - t_first;
-                    if (k0 < XPW) issue_x(c + 1, k0);
-                    if (tap == 8)
-                        for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
+            auto refill = [&]() __attribute__((always_inline)) {
+                if constexpr (SLICED) {
+                    if (c < c_last && !(ABL & 2)) {
+                        const int k0 = tap - t_first;
+                        if (k0 < XPW) issue_x(c + 1, k0);
+                        if (tap == 8)
+                            for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
+                    }
+                } else {
+                    if (c + 1 < ncht && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
                 }
-            } else {
-                if (NXB == 2 && c + 1 < ncht && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
-            }
-            // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
-            if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+                // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
+                if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+            };
+            if constexpr (SCHED == 0) refill();
             const char* wb = smem + WBASE + (NSLOT == 3 ? tap % 3 : (s & 1)) * WSLOT + la;
             const int ky = tap / 3, kx = tap % 3;
-            // the stage's MFMAs (fragment reads of the nine shifted halo rows + the weight tile)
-            auto compute = [&]() __attribute__((always_inline)) {
-                if constexpr (SPLIT) {
-                    f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+            // the stage's MFMAs (fragment reads of the nine shifted halo rows + the weight tile) and, SCHED = 1, its refill between them (see the
+            // header): waves 0 - 3 refill in front of their MFMAs, waves 4 - 7 behind the first SCH_AT channel fragments
+            const bool first_half = wave < NWV / 2;   // (scalar)
+            if constexpr (SPLIT) {
+                constexpr int SCH_AT = FC >= 4 ? 3 : 2;
+                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+                // (in the order the MFMAs want them: LDS returns are in order, the first product needs ah[0] and the hi pixel fragments)
+                ah[0] = *(const f16x8*)(wb + swz0);
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) {
-                        bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
-                        bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
-                    }
+                for (int j = 0; j < FP; ++j) bh[j] = *(const f16x8*)(smem + xfo[j][kx] + ky * HWD * 128);
 #pragma unroll
-                    for (int i = 0; i < FC; ++i) {
-                        ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
-                        al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
-                    }
+                for (int j = 0; j < FP; ++j) bl[j] = *(const f16x8*)(smem + xor64(xfo[j][kx]) + ky * HWD * 128);
+                al[0] = *(const f16x8*)(wb + swz1);
 #pragma unroll
-                    for (int i = 0; i < FC; ++i) {
+                for (int i = 1; i < FC; ++i) {
+                    ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                    al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+                }
+                auto mm = [&](auto i0_tag, auto i1_tag) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) {
                         const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
 #pragma unroll
                         for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
@@ -464,37 +454,59 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
 #pragma unroll
                         for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     }
+                };
+                if constexpr (SCHED == 0) {
+                    mm(std::integral_constant<int, 0>{}, std::integral_constant<int, FC>{});
+                } else if constexpr (SCHED == 2) {   // (A/B builds: every wave refills behind its first channel fragment's MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    refill();
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(std::integral_constant<int, 1>{}, std::integral_constant<int, FC>{});
                 } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (first_half) refill();
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(std::integral_constant<int, 0>{}, std::integral_constant<int, SCH_AT>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!first_half) refill();
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(std::integral_constant<int, SCH_AT>{}, std::integral_constant<int, FC>{});
+                }
+            } else {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        if (ks == 1 && !two) break;
-                        const int sw = ks ? swz1 : swz0;
-                        f16x8 a[FC], bf[FP];
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks == 1 && !two) break;
+                    const int sw = ks ? swz1 : swz0;
+                    f16x8 a[FC], bf[FP];
 #pragma unroll
-                        for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
+                    for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
 #pragma unroll
-                        for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
+                    for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][kx]) : xfo[j][kx]) + ky * HWD * 128);
+                    if constexpr (SCHED == 1) {
+                        if (ks == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (first_half) refill();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
 #pragma unroll
-                        for (int i = 0; i < FC; ++i)
+                    for (int i = 0; i < FC; ++i)
 #pragma unroll
-                            for (int j = 0; j < FP; ++j) {
-                                if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
-                            }
+                        for (int j = 0; j < FP; ++j) {
+                            if (ABL & 4) { acc[i][j][0] += (float)(a[i][0] * bf[j][0]); continue; }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                        }
+                    if constexpr (SCHED != 0) {
+                        if (ks == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (SCHED == 2 || !first_half) refill();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
-            };
-            if (EARLY && tap >= 7 && early) {
-                // the two waves of a SIMD (w and w + 4: a workgroup's waves go to the SIMDs in cyclic order) take the two halves of
-                // the stage in opposite order: while one is in the GroupNorm VALU code the other keeps the matrix pipe busy
-                auto piece = [&]() __attribute__((always_inline)) {
-                    if (tap == 7) apply_cells(c + 1, cf_next, std::integral_constant<int, 0>{}, std::integral_constant<int, NC_HALF>{});
-                    else apply_cells(c + 1, cf_next, std::integral_constant<int, NC_HALF>{}, std::integral_constant<int, NC_ALL>{});
-                };
-                if (wave < 4) { piece(); __builtin_amdgcn_sched_barrier(0); compute(); }
-                else { compute(); __builtin_amdgcn_sched_barrier(0); piece(); }
-                if (tap == 8) pre_applied = true;
-            } else compute();
+            }
         }
     }
     if constexpr (SKIPOK) {
@@ -522,26 +534,44 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             // (the refills of a wave stay in the order halo pieces, then weight tile: the counted wait above relies on the tile being youngest)
             if (s + NSLOT - 1 < nst) issue_w(s + NSLOT - 1, NSLOT == 3 ? (s + 2) % 3 : ((s + 1) & 1));
             const char* wb = smem + WBASE + (NSLOT == 3 ? s % 3 : (s & 1)) * WSLOT + la;
-            f16x8 ah[FC], al[FC], bh[FP], bl[FP];
+            if constexpr (SPLIT) {
+                f16x8 ah[FC], al[FC], bh[FP], bl[FP];
 #pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                bh[j] = *(const f16x8*)(smem + xfo[j][1] + HWD * 128);
-                bl[j] = *(const f16x8*)(smem + xor64(xfo[j][1]) + HWD * 128);
-            }
+                for (int j = 0; j < FP; ++j) {
+                    bh[j] = *(const f16x8*)(smem + xfo[j][1] + HWD * 128);
+                    bl[j] = *(const f16x8*)(smem + xor64(xfo[j][1]) + HWD * 128);
+                }
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
-                al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
-            }
+                for (int i = 0; i < FC; ++i) {
+                    ah[i] = *(const f16x8*)(wb + swz0 + i * 2048);
+                    al[i] = *(const f16x8*)(wb + swz1 + i * 2048);
+                }
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // exact (|w| < 30: the engine folds no shortcut with larger weights)
+                for (int i = 0; i < FC; ++i) {
+                    const f16x8 as = ah[i] * (f16)RS_LO_SCALE;   // exact (|w| < 30: the engine folds no shortcut with larger weights)
 #pragma unroll
-                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+                const bool two2 = (c - nch) * 64 + 64 <= sC;   // (a half chunk: one k-step of 32 channels)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks == 1 && !two2) break;
+                    const int sw = ks ? swz1 : swz0;
+                    f16x8 a[FC], bf[FP];
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) a[i] = *(const f16x8*)(wb + sw + i * 2048);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) bf[j] = *(const f16x8*)(smem + (ks ? xor64(xfo[j][1]) : xfo[j][1]) + HWD * 128);
+#pragma unroll
+                    for (int i = 0; i < FC; ++i)
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -886,7 +916,7 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
     p.w_bytes = (unsigned)wb;
     if (p.sx) {   // folded 1x1 shortcut: only where the kernel carries it (see SKIPOK), whole 32-channel chunks, 16-byte rows
         const size_t sxb = (size_t)p.B * p.Hs * p.Ws * p.sld * esz, swb = (size_t)p.Cout * p.sC * esz;
-        if (!SPLIT || SEG != 0 || NWV != 8 || sk > 1 || !p.sw || p.sC < 32 || (p.sC % 32) || (p.sld % 8) || p.sld < p.sC || sxb >= 0xF0000000ull ||
+        if (SEG != 0 || NWV != 8 || sk > 1 || !p.sw || p.sC < 32 || (p.sC % 32) || (p.sld % 8) || p.sld < p.sC || sxb >= 0xF0000000ull ||
             ((uintptr_t)p.sx & 15) || ((uintptr_t)p.sw & 15))
             return hipErrorInvalidValue;
         p.sx_bytes = (unsigned)sxb;
@@ -898,10 +928,6 @@ hipError_t launch4_cfg(IGemmParams p, hipStream_t st) {
         const int per_image = SEG == 16 ? 1 : (p.Ho / TH) * (p.Wo / TW);
         p.tail.expected = per_image * ((p.Cout + BC - 1) / BC);
         p.tail.st0 = p.ystats; p.tail.S0 = per_image; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
-    }
-    {   // A/B knob: RS_IG4_EARLY_GN=1 lets the GroupNorm pass of chunk c + 1 ride on taps 7 / 8 of chunk c
-        static const bool early = []() { const char* v = getenv("RS_IG4_EARLY_GN"); return v && v[0] == '1'; }();   // measured: no gain (profiles/r3_igemm4_early_gn.txt)
-        p.dbg = early ? 0 : 16;
     }
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if constexpr (!SPLIT && BC == 160 && SEG == 0 && NWV == 8) {

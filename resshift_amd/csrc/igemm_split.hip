@@ -602,6 +602,12 @@ extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC) {
     *BC = best;
     const long long tiles128 = (long long)((M + 127) / 128) * ((Cout + best - 1) / best) * nz;
     *BP = (tiles128 < 256) ? 64 : 128;
+    // Down to 64 tiles the 128-pixel tile stays on 8 waves and the split-K planner fills the chip with K slices instead (M = 8192, N = 320:
+    // 128 tiles x 2 slices of 8 waves - two waves per SIMD on every CU, half the K loop per workgroup, + the reduce kernel - against 256
+    // tiles of 4 waves, one wave per SIMD: 68 us for 18 us of MFMA work).  Measured in round 5 (profiles/r5_fold_ab.txt): igemm_split family
+    // 51.9 -> 49.0 ms per parity pass, the pass - 2.1 ms, + 210 reduce launches.  RS_SPLIT_BP128_SK=0: the round-4 choice.
+    static const int bp128_min = []() { const char* e = getenv("RS_SPLIT_BP128_SK"); return e ? atoi(e) : 64; }();
+    if (bp128_min > 0 && nz == 1 && tiles128 >= bp128_min) *BP = 128;
 }
 
 // pixels per statistics slab of an igemm_split launch that is asked for IGemmParams::ystats (0: it cannot produce them): the pixel tile,

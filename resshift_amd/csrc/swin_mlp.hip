@@ -313,13 +313,20 @@ struct MlpSplitParams {
     GNTail tail;          // ... and with tail.coef that GroupNorm's coefficients too (gn_tail.h)
 };
 
-template <int E, int HD>
+// NO != E: the layer's patch_unembed (models/swin_transformer.py:515,521-528: a 1x1 conv E -> NO behind the last block, no norm in the shipped
+// configs) folded into this launch.  y = Wu (x + fc2(h) + b2) + bu = [Wu W2 | Wu] [h ; x] + (Wu b2 + bu): GEMM2 runs on the product matrix
+// (packed by the engine: `w2` = [NO][HD + E] columns, hi | lo; `b2` = the merged bias, NO floats) with NO output rows, and the block's
+// shortcut becomes KC more K steps whose token operand is the RAW x (re-read into the token-fragment registers once GEMM1 has used them
+// for the last time - the same bytes the residual read costs the unfused form).  No `res`; y has NO channels; the statistics are y's.
+template <int E, int HD, int NO = E>
 __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p) {
+    constexpr bool FOLD = NO != E;
     constexpr int BP = 128, HS = 32, NST = HD / HS, KC = E / 32;     // tokens per workgroup, hidden units per step, steps, K chunks
-    constexpr int W1_SLOT = KC * HS * 128, W2_SLOT = E * 128;        // 24 KB each
+    constexpr int NSTT = FOLD ? NST + KC : NST, HDT = FOLD ? HD + E : HD;   // steps / K columns of GEMM2 incl. the folded shortcut
+    constexpr int W1_SLOT = KC * HS * 128, W2_SLOT = NO * 128;       // 24 KB / 20 - 24 KB
     constexpr int W1R = 0, W2R = 2 * W1_SLOT, PS = W2R + 2 * W2_SLOT;
-    constexpr int FC2 = E / 32;                                      // channel fragments per wave in GEMM2 (wave covers E/2 channels)
-    static_assert(E % 64 == 0 && HD % HS == 0 && PS + BP * 128 <= 160 * 1024, "shape");
+    constexpr int FC2 = NO / 32;                                     // channel fragments per wave in GEMM2 (wave covers NO/2 channels)
+    static_assert(E % 64 == 0 && NO % 32 == 0 && NO <= E && HD % HS == 0 && PS + BP * 128 <= 160 * 1024, "shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -330,23 +337,26 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
     const int m0 = blockIdx.x * BP;
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(HD * E * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(HD * E * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(HDT * NO * 4), 0x00020000);
     // weights of one step -> ring slot.  W1 (rows [E hi | E lo]): 6 chunks x 32 hidden rows = 24 one-KB pieces, 3 per wave;
     // W2 (rows [HD hi | HD lo]): 192 channel rows = 24 pieces, 3 per wave
     auto issue_w = [&](int t, int slot) {
         const unsigned plane = (unsigned)(kcp >> 2), sub = (unsigned)(kcp & 3) * 8u;
+        if (!FOLD || t < NST) {   // (workgroup-uniform; the folded shortcut's steps have no W1 part)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int piece = wave * 3 + q;                 // 0..23: chunk = piece / 4, row group = piece % 4
-            const int c = piece >> 2, rg = piece & 3;
-            const unsigned n = (unsigned)(t * HS + rg * 8 + (lane >> 3));
-            lds_dma16(r1, smem + W1R + slot * W1_SLOT + piece * 1024, (n * (unsigned)(2 * E) + plane * (unsigned)E + (unsigned)(c * 32) + sub) * 2u);
+            for (int q = 0; q < 3; ++q) {
+                const int piece = wave * 3 + q;                 // 0..23: chunk = piece / 4, row group = piece % 4
+                const int c = piece >> 2, rg = piece & 3;
+                const unsigned n = (unsigned)(t * HS + rg * 8 + (lane >> 3));
+                lds_dma16(r1, smem + W1R + slot * W1_SLOT + piece * 1024, (n * (unsigned)(2 * E) + plane * (unsigned)E + (unsigned)(c * 32) + sub) * 2u);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int piece = wave * 3 + q;                 // rows 8 piece ..
+            if (NO < 192 && piece * 8 >= NO) continue;      // (wave-uniform; NO = 160: 20 of the 24 pieces)
             const unsigned n = (unsigned)(piece * 8 + (lane >> 3));
-            lds_dma16(r2, smem + W2R + slot * W2_SLOT + piece * 1024, (n * (unsigned)(2 * HD) + plane * (unsigned)HD + (unsigned)(t * HS) + sub) * 2u);
+            lds_dma16(r2, smem + W2R + slot * W2_SLOT + piece * 1024, (n * (unsigned)(2 * HDT) + plane * (unsigned)HDT + (unsigned)(t * HS) + sub) * 2u);
         }
     };
     RS_MLP_STAMP(0);
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         const int slot = t & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t have landed
         __builtin_amdgcn_s_barrier();                        // ... everybody's; GEMM2 of step t-1 is finished everywhere (P and the other slot are free)
-        if (t + 1 < NST) issue_w(t + 1, slot ^ 1);
+        if (t + 1 < NSTT) issue_w(t + 1, slot ^ 1);
         const f32x4 bv = *(const f32x4*)(p.b1 + t * HS + wc * 16 + lg * 4);
         // ---- GEMM1: S[hidden 16 of this wave][32 tokens] over K = E (accumulator carries 2^11 x the sum)
         f32x4 s_[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -402,6 +412,17 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
                 s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, xh[c][j], s_[j], 0, 0, 0);
                 s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[c][j], s_[j], 0, 0, 0);
                 s_[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[c][j], s_[j], 0, 0, 0);
+            }
+        }
+        if (FOLD && t == NST - 1) {
+            // GEMM1 has read the (normalised) token fragments for the last time: the registers take the RAW tokens, the operand of the folded
+            // shortcut's K steps; the loads travel under this step's activation math and GEMM2 (the next step's vmcnt(0) covers them)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = min(m0 + wp * 32 + j * 16 + lr, p.M - 1);
+                const f16* xr = p.x + (long long)m * p.ldx * 2 + lg * 8;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) { xh[c][j] = *(const f16x8*)(xr + c * 32); xl[c][j] = *(const f16x8*)(xr + p.ldx + c * 32); }
             }
         }
         // ---- bias + GELU -> (hi, lo) hidden activations P[token][32 hidden] in LDS (a lane holds hidden h..h+3 of token m)
@@ -423,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         __builtin_amdgcn_s_barrier();
         // ---- GEMM2: O[c][m] += W2[c][h..h+32] . P[m][..], wave tile (E/2) channels x 32 tokens, K = 32
         {
-            const char* pa = smem + W2R + slot * W2_SLOT + (wc * (E / 2) + lr) * 128;
+            const char* pa = smem + W2R + slot * W2_SLOT + (wc * (NO / 2) + lr) * 128;
             const char* pb = smem + PS + (wp * 32 + lr) * 128;
             f16x8 bh[2], bl[2];
 #pragma unroll
@@ -444,16 +465,38 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         if (t == 0) RS_MLP_STAMP(2);
 #endif
     }
+    if constexpr (FOLD) {
+        // ---- the folded shortcut: KC more K steps of GEMM2, columns [Wu] of the product matrix against the raw tokens (registers)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int t = NST + c, slot = t & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of step t (and, c = 0, its raw tokens) have landed
+            __builtin_amdgcn_s_barrier();                        // ... everybody's; the other slot is free
+            if (t + 1 < NSTT) issue_w(t + 1, slot ^ 1);
+            const char* pa = smem + W2R + slot * W2_SLOT + (wc * (NO / 2) + lr) * 128;
+#pragma unroll
+            for (int i = 0; i < FC2; ++i) {
+                const f16x8 ah = *(const f16x8*)(pa + i * 2048 + swh), al = *(const f16x8*)(pa + i * 2048 + swl);
+                const f16x8 as = ah * (f16)RS_LO_SCALE;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, xh[c][j], o[i][j], 0, 0, 0);
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[c][j], o[i][j], 0, 0, 0);
+                    o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[c][j], o[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
     RS_MLP_STAMP(3);
     __syncthreads();   // every read of the rings / P has retired: the front of the LDS becomes the output staging area
     RS_MLP_STAMP(4);
 
     // ---- epilogue: 2^-11 O + b2 + residual, then the hi and the lo halves through LDS into 16-byte stores
-    constexpr int ROWB = (E / 2) * 2 + 16;
+    constexpr int ROWB = (NO / 2) * 2 + 16;
     char* stg = smem + wave * 32 * ROWB;
     // (the residual of the whole wave tile in flight at once - 48 registers, the token fragments are dead by now: loaded per
     // fragment it was twelve L2 round trips in a row)
-    const bool res_ok = p.res != nullptr;
+    const bool res_ok = !FOLD && p.res != nullptr;
     f16x4 rh[FC2][2], rl[FC2][2];
     if (res_ok) {
 #pragma unroll
@@ -461,14 +504,14 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
             const long long mr = (long long)min(m0 + wp * 32 + j * 16 + lr, p.M - 1) * p.ldres * 2;
 #pragma unroll
             for (int i = 0; i < FC2; ++i) {
-                const int n = wc * (E / 2) + i * 16 + lg * 4;
+                const int n = wc * (NO / 2) + i * 16 + lg * 4;
                 rh[i][j] = *(const f16x4*)(p.res + mr + n); rl[i][j] = *(const f16x4*)(p.res + mr + p.ldres + n);
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < FC2; ++i) {
-        const int n = wc * (E / 2) + i * 16 + lg * 4;
+        const int n = wc * (NO / 2) + i * 16 + lg * 4;
         const f32x4 bv = *(const f32x4*)(p.b2 + n);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -484,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
     // wave 0 adds the four token-waves in a fixed order, publishes the tile's pairs and - GroupNorm tail - draws the image's ticket while the
     // other waves are already storing (gn_tail.h)
     float* const sb = (float*)(smem + 8 * 32 * ROWB);                 // [8 waves][E / 2][2]
-    unsigned* const tail_flag = (unsigned*)(sb + 8 * (E / 2) * 2);
+    unsigned* const tail_flag = (unsigned*)(sb + 8 * (NO / 2) * 2);
     const bool tail_on = p.ystats != nullptr && p.tail.coef != nullptr;
     const int img = m0 / (p.HW > 0 ? p.HW : 1);
     if (p.ystats) {
@@ -493,16 +536,16 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = rs_sum16(o[i][0][r] + o[i][1][r]), q = rs_sum16(fmaf(o[i][0][r], o[i][0][r], o[i][1][r] * o[i][1][r]));
-                if (lr == 0) { sb[(wave * (E / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (E / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
+                if (lr == 0) { sb[(wave * (NO / 2) + i * 16 + lg * 4 + r) * 2] = a; sb[(wave * (NO / 2) + i * 16 + lg * 4 + r) * 2 + 1] = q; }
             }
         __syncthreads();
         if (wave == 0) {
             float* dst = p.ystats + (((long long)img * (p.HW >> 7) + ((m0 - img * p.HW) >> 7)) * p.ystats_ld) * 2;
-            for (int c = lane; c < E; c += 64) {
-                const int hw_ = c / (E / 2), cl = c - hw_ * (E / 2);   // channel-wave, channel inside its half
+            for (int c = lane; c < NO; c += 64) {
+                const int hw_ = c / (NO / 2), cl = c - hw_ * (NO / 2);   // channel-wave, channel inside its half
                 float a = 0.f, q = 0.f;
 #pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (E / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (E / 2) + cl) * 2 + 1]; }
+                for (int w4 = 0; w4 < 4; ++w4) { a += sb[((hw_ * 4 + w4) * (NO / 2) + cl) * 2]; q += sb[((hw_ * 4 + w4) * (NO / 2) + cl) * 2 + 1]; }
                 if (tail_on) rs_pub_pair(dst + c * 2, a, q);
                 else { dst[c * 2] = a; dst[c * 2 + 1] = q; }
             }
@@ -510,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
         }
     }
     RS_MLP_STAMP(5);
-    constexpr int CPR = (E / 2) / 8, NITEM = 32 * CPR;
+    constexpr int CPR = (NO / 2) / 8, NITEM = 32 * CPR;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -527,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_split_kernel(MlpSplitParams p
             const int row = idx / CPR, c8 = idx - row * CPR;
             const int m = m0 + wp * 32 + row;
             if (m >= p.M) continue;
-            *(uint4*)(p.y + (long long)m * p.ldy * 2 + half * p.ldy + wc * (E / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
+            *(uint4*)(p.y + (long long)m * p.ldy * 2 + half * p.ldy + wc * (NO / 2) + c8 * 8) = *(const uint4*)(stg + row * ROWB + c8 * 16);
         }
         RS_STAGING_SYNC();   // wave-private staging tile: the wave's own LDS order suffices, no workgroup barrier
     }
@@ -556,12 +599,20 @@ extern "C" int rs_mlp_phase_cycles(int nwg, double* out6) {
 #endif
 
 // split storage: x / res / y tensors of (hi, lo) pairs, w1 / w2 packed [rows][K hi | K lo]
-extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
-                                        int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld,
-                                        const GNTail* tail, hipStream_t st) {
+// patch_unembed folded into the layer's last fused MLP (the kernel's NO != E form): the output widths this build instantiates
+extern "C" int rs_swin_mlp_split_unembed_supported(int E, int HD, int NO) { return E == 192 && HD == 768 && NO == 160; }
+
+// `NO` = 0 (or E): the block alone, y = x' + fc2(gelu(fc1(norm2(x)))) with `res` = x'.  NO != E: + patch_unembed - `w2` is the product matrix
+// [NO][HD + E] (hi | lo), `b2` the merged bias (NO floats), `res` must be null (the shortcut is the RAW `x`, which therefore has to be the
+// block's own input: xcoef set), y has NO channels.
+extern "C" int rs_swin_mlp_split_launch_n(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
+                                          int M, int ldx, int ldres, int ldy, int E, int HD, int NO, const float* xcoef, int HW, float* ystats,
+                                          int ystats_ld, const GNTail* tail, hipStream_t st) {
+    if (NO <= 0) NO = E;
     if (ystats && (HW <= 0 || (HW & 127) || (M & 127))) return -2;   // one statistics set per 128-token tile of one image
     if (tail && tail->coef && !ystats) return -2;
     if (!rs_swin_mlp_supported(E, HD) || (ldx & 7) || (ldy & 7) || (res && (ldres & 3)) || M <= 0) return -2;
+    if (NO != E && (!rs_swin_mlp_split_unembed_supported(E, HD, NO) || res || !xcoef)) return -2;
     if (xcoef && (HW <= 0 || HW % 128)) return -2;
     MlpSplitParams p{};
     p.x = (const f16*)x; p.w1 = (const f16*)w1; p.b1 = b1; p.w2 = (const f16*)w2; p.b2 = b2; p.res = (const f16*)res; p.y = (f16*)y;
@@ -569,13 +620,21 @@ extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const flo
     if (tail && tail->coef) {   // GroupNorm tail: this launch's statistics are segment 0; every 128-token tile of an image arrives once
         p.tail = *tail;
         p.tail.expected = HW / 128;
-        p.tail.st0 = ystats; p.tail.S0 = HW / 128; p.tail.ld0 = ystats_ld; p.tail.n0 = E;
+        p.tail.st0 = ystats; p.tail.S0 = HW / 128; p.tail.ld0 = ystats_ld; p.tail.n0 = NO;
     }
-    constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688
+    constexpr int LDS = 2 * 6 * 32 * 128 + 2 * 192 * 128 + 128 * 128;   // 114688 (NO = 160: 8 KB less; one size keeps it simple)
     static RsAttrFlags attr_flags;
     if (attr_flags.need()) {
         (void)hipFuncSetAttribute((const void*)swin_mlp_split_kernel<192, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)swin_mlp_split_kernel<192, 768, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
-    hipLaunchKernelGGL((swin_mlp_split_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
+    if (NO == 160) hipLaunchKernelGGL((swin_mlp_split_kernel<192, 768, 160>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
+    else hipLaunchKernelGGL((swin_mlp_split_kernel<192, 768>), dim3((M + 127) / 128), dim3(512), LDS, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int rs_swin_mlp_split_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* res, void* y,
+                                        int M, int ldx, int ldres, int ldy, int E, int HD, const float* xcoef, int HW, float* ystats, int ystats_ld,
+                                        const GNTail* tail, hipStream_t st) {
+    return rs_swin_mlp_split_launch_n(x, w1, b1, w2, b2, res, y, M, ldx, ldres, ldy, E, HD, E, xcoef, HW, ystats, ystats_ld, tail, st);
 }

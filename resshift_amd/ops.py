@@ -223,6 +223,25 @@ def swin_mlp(x, w1, b1, w2, b2, res=None):
     return y
 
 
+def swin_mlp_unembed(x, coef, hw, w1, b1, w2, b2, wu, bu):
+    """Last Swin block's MLP half + patch_unembed in one launch (split storage): x [M, E] int32 (hi, lo) pairs = the block's raw input,
+    coef [M / hw, 2, E] fp32 = norm2's per-image affine; returns [M, NO] split.  The product matrix [Wu W2 | Wu] and the merged bias are
+    formed here in float64 exactly like the engine's packer (engine.hip: add_basiclayer)."""
+    lib = _lib.load()
+    M, E = x.shape
+    HD, NO = w1.shape[0], wu.shape[0]
+    wcat = torch.cat([wu.double() @ w2.double(), wu.double()], dim=1).float()
+    bcat = (wu.double() @ b2.double() + bu.double()).float()
+    w1d, wcd = split_pack_rows(w1).to(x.device), split_pack_rows(wcat).to(x.device)
+    b1d, bcd = b1.to(x.device, torch.float32).contiguous(), bcat.to(x.device).contiguous()
+    cd = coef.to(x.device, torch.float32).contiguous()
+    y = torch.empty(M, NO, device=x.device, dtype=x.dtype)
+    rc = lib.rs_op_swin_mlp_split_unembed(x.data_ptr(), cd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), wcd.data_ptr(), bcd.data_ptr(), y.data_ptr(),
+                                          M, hw, E, HD, NO, _lib.current_stream_ptr())
+    _lib.check(rc, "swin_mlp_unembed")
+    return y
+
+
 def softmax_rows(s, out_prec=F32):
     lib = _lib.load()
     nrows, ncols = s.shape

@@ -407,6 +407,31 @@ def test_swin_mlp_fused_split(gpu, M, use_res):
     _close(y, ref.float(), 3e-6, f"split swin mlp M={M}")
 
 
+@pytest.mark.parametrize("B,hw", [(1, 128), (3, 256), (2, 4096)])
+def test_swin_mlp_fused_split_with_patch_unembed(gpu, B, hw):
+    """swin_mlp_split_kernel<192, 768, 160>: norm2's affine, fc1, GELU, fc2, the block's shortcut AND the layer's patch_unembed
+    (models/swin_transformer.py:279,515,521-528) as one launch - fc2 runs on the product matrix Wu W2, the shortcut as six more K steps of Wu
+    on the raw tokens - against torch fp64 of the unfused sequence on the unrounded operands."""
+    from resshift_amd import ops
+
+    E, HD, NO = 192, 768, 160
+    M = B * hw
+    g = torch.Generator().manual_seed(B * 1000 + hw)
+    x = torch.randn(M, E, generator=g)
+    a, d = 1.0 + 0.3 * torch.randn(B, E, generator=g), 0.2 * torch.randn(B, E, generator=g)
+    w1 = torch.randn(HD, E, generator=g) / math.sqrt(E)
+    w2 = torch.randn(E, HD, generator=g) / math.sqrt(HD)
+    wu = torch.randn(NO, E, generator=g) / math.sqrt(E)
+    b1, b2, bu = torch.randn(HD, generator=g) * 0.3, torch.randn(E, generator=g) * 0.3, torch.randn(NO, generator=g) * 0.3
+    xs = ops.convert(x.to(gpu), ops.SPLIT)
+    y = ops.convert(ops.swin_mlp_unembed(xs, torch.stack([a, d], dim=1), hw, w1, b1, w2, b2, wu, bu), ops.F32)
+    torch.cuda.synchronize()
+    xd = x.double().view(B, hw, E)
+    xn = (xd * a.double()[:, None, :] + d.double()[:, None, :]).view(M, E)
+    ref = (x.double() + F.gelu(xn @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()) @ wu.double().t() + bu.double()
+    _close(y, ref.float(), 4e-6, f"split swin mlp + unembed B={B} hw={hw}")
+
+
 @pytest.mark.parametrize("hw,shift", [((16, 16), 0), ((16, 16), 4), ((8, 8), 0), ((24, 16), 4), ((64, 64), 4)])
 def test_window_attention_fused_qkv(gpu, hw, shift):
     """win_attn_qkv_kernel: qkv Linear (swin_transformer.py:85,121) + window attention in one launch, against the torch
