@@ -603,6 +603,7 @@ def main():
                        "parallelism": f"dp{world} (batch sharded, one RCCL weight broadcast, no data-path collective)"},
             "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                       "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "rccl_version": sharding.dist_info()["rccl_version"],
                       "gpus_visible": torch.cuda.device_count(),
                       "per_rank": [{"rank": r, "device": int(v[1]), "images_per_sec": round(B * args.steps / v[0], 3)} for r, v in enumerate(per_rank)],
                       "weight_broadcast_bytes": int(getattr(eng, "broadcast_bytes", 0)),
@@ -614,7 +615,7 @@ def main():
         line.update(extra)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
-        dist.barrier()
+        sharding.barrier()
         dist.destroy_process_group()
 
 

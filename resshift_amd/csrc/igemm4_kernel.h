@@ -52,6 +52,10 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, char* lds, u
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, 0, 0, 0);
 }
 
+__device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t r, char* lds, unsigned voff, unsigned soff) {   // + a scalar byte offset
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
 // k-step 1 of a fragment address (chunk index ^ 4 = byte ^ 64), computed where it is used: as plain C++ the compiler hoists all
 // twelve variants out of the tap loop and the kernel spills
 __device__ __forceinline__ int xor64(int v) {
@@ -75,6 +79,19 @@ __device__ long long g_ig4_clk[4 * 8192];   // per workgroup: cycle counter at k
 // SCHED = 1 every wave issues its fragment reads first; the waves 0 - 3 then refill and go on to their MFMAs, the waves 4 - 7 (the
 // other wave of each SIMD: a workgroup's waves go to the SIMDs in cyclic order) run the first SCH_AT channel fragments' MFMAs, refill,
 // and finish - whichever wave of a SIMD is in its address arithmetic, the other one keeps the matrix pipe fed.
+// s_waitcnt vmcnt(n) for an n that is a constant once the tap loop is unrolled (the asm immediate itself must be a literal)
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+}
+
 template <int TW, int BC, bool SPLIT, int SEG = 0, int ABL = 0, int NWV = 8>
 __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     static_assert(SEG == 0 || (TW == 32 && (SEG == 8 || SEG == 16)), "segmented tiles use the 8 x 32 geometry");
@@ -82,10 +99,34 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     constexpr int NT = 64 * NWV, WPX = NWV / 2;   // threads; pixel-waves (x 2 channel-waves)
     constexpr int NXB = 2;                        // halo buffers
     constexpr int LDSCAP = 160 * 1024;
-#ifndef RS_IG4_SCHED
-#define RS_IG4_SCHED 1
-#endif
+    // Measured (profiles/r5_halo_refill_ab.txt, scripts/igemm_bench.py, conv layer mix of one pass): split storage 152.2 ms (round 4) ->
+    // 144.9 with SCHED 2 (SCHED 1: 152.7 - its late refills leave a wave's weight tile less than a stage to land); fp16 66.9 -> 62.8 with
+    // SCHED 1 (SCHED 2: 64.1).  Default: 2 for split storage, 1 for fp16.  -DRS_IG4_SCHED=n forces one form (A/B builds).
+#ifdef RS_IG4_SCHED
     constexpr int SCHED = (ABL == 0) ? RS_IG4_SCHED : 0;
+#else
+    constexpr int SCHED = (ABL != 0) ? 0 : (SPLIT ? 2 : 1);
+#endif
+#ifndef RS_IG4_FAST
+#define RS_IG4_FAST 1
+#endif
+#ifndef RS_IG4_PRIO
+#define RS_IG4_PRIO 1
+#endif
+    // XPF (round 5, split storage, big planes): the pixel fragments of tap t + 1 are read from the halo buffer while tap t's last MFMAs
+    // run - the halo chunk is complete and untouched for all nine taps, only the WEIGHT tile is what a stage's barrier waits for - and
+    // the weight fragments are read one channel fragment ahead instead of all at once.  Behind a barrier the first MFMA then waits for
+    // one weight fragment instead of nine reads of an LDS that all eight waves hit together (and the fragment registers stay at 84).
+#ifndef RS_IG4_XPF
+#define RS_IG4_XPF 1
+#endif
+    constexpr bool XPF = SPLIT && SEG == 0 && ABL == 0 && RS_IG4_XPF;
+    // FAST (round 5): the refill's per-lane byte offsets - XPW halo pieces and RW weight row groups of this wave - are computed ONCE and
+    // kept in registers (10 VGPRs); what changes from stage to stage (chunk, tap) is a scalar and travels in the buffer instruction's
+    // SGPR offset.  A stage's refill shrinks from ~100 instructions (pixel decode, bounds tests, 32-bit multiplies, per piece and row
+    // group, in every one of the 9 nch stages) to the four LDS-DMA instructions and a handful of scalar ones.  The folded shortcut's
+    // chunks / tiles (another base, pitch and row length; a few stages at the end of the loop) keep the general code.
+    constexpr bool FAST = SEG == 0 && ABL == 0 && RS_IG4_FAST;
     constexpr int KC = SPLIT ? 32 : 64;         // input channels per chunk (one 128-byte LDS row per pixel / weight row)
     // halo row pitch HWD: TW + 2 rounded up to a multiple of 8, so that a tap's row shift ky * HWD leaves (row & 7) - the LDS
     // swizzle key - unchanged: the nine shifted fragment addresses of a lane are 3 bases (kx) + an immediate offset (ky)
@@ -100,6 +141,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     constexpr int FP = 4, FC = BC / 32;
     constexpr int XPIECES = HROWS_P / 8;        // 1 KB LDS-DMA pieces (8 halo rows x 128 B) of one chunk
     constexpr int XPW = (XPIECES + NWV - 1) / NWV;      // pieces per wave (wave w owns pieces w, w + NWV, ...)
+    constexpr int XPWF = XPIECES / NWV;                 // ... of which every wave has this many
     constexpr int RR = 8 * NWV;                         // weight rows covered by one LDS-DMA instruction of every wave
     constexpr int RWF = BC / RR, RWP = BC % RR, RW = RWF + (RWP ? 1 : 0);
     constexpr int NCELL = (HROWS_P * 8 + NT - 1) / NT;  // 16-byte LDS cells per thread in the in-LDS GroupNorm pass
@@ -226,6 +268,41 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             const int n = n0 + RR * i + rr;
             const bool ok = RR * i + rr < BC && n < Cout && cb < (unsigned)Cin;
             lds_dma16(rw, sbase + (RR * i) * 128, ok ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + kb : INV);
+        }
+    };
+
+    unsigned xv[XPW], wv[RW];   // FAST: byte offset of this lane's 16 bytes in piece k / row group i at chunk 0, tap 0 (INV: zeros)
+    if constexpr (FAST) {
+        const unsigned lpart = SPLIT ? (unsigned)(kcp >> 2) * (unsigned)ld0 * 2u + (unsigned)(kcp & 3) * 16u : (unsigned)kcp * 16u;
+#pragma unroll
+        for (int k = 0; k < XPW; ++k) {
+            unsigned pix; int img;
+            const bool inside = halo_src(8 * (wave + NWV * k) + (lane >> 3), pix, img);
+            xv[k] = (inside && wave + NWV * k < XPIECES) ? pix * (unsigned)ld0 * (SPLIT ? 4u : 2u) + lpart : INV;
+        }
+        const unsigned wpart_l = SPLIT ? (unsigned)(kcp >> 2) * (unsigned)Ktot * 2u + (unsigned)(kcp & 3) * 16u : (unsigned)kcp * 16u;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int n = n0 + RR * i + rr;
+            wv[i] = (RR * i + rr < BC && n < Cout) ? (unsigned)n * (unsigned)Ktot * (SPLIT ? 4u : 2u) + wpart_l : INV;
+        }
+    }
+    // main-source piece k of chunk c (c < nch) / main weight tile of stage s (s < 9 nch) from the precomputed offsets
+    auto issue_x_fast = [&](int c, int k) __attribute__((always_inline)) {
+        if (wave + NWV * k >= XPIECES) return;                       // wave-uniform
+        unsigned v = xv[k];
+        if constexpr (!SPLIT) v = (c * 64 + 64 > Cin && kcp >= 4) ? INV : v;   // half chunk: its upper 32 channels do not exist
+        lds_dma16s(rx, smem + (c & 1) * XBUF + (wave + NWV * k) * 1024, v, (unsigned)(c * KC) * 2u);
+    };
+    auto issue_w_fast = [&](int s, int slot) __attribute__((always_inline)) {
+        char* sbase = smem + WBASE + slot * WSLOT + (8 * wave) * 128;
+        const int c = s / 9, tap = s - c * 9;
+        const unsigned so = (unsigned)(tap * Cin + c * KC) * 2u;
+        const bool halfc = !SPLIT && c * 64 + 64 > Cin;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            if (RWP && i == RW - 1 && !wpart) continue;
+            lds_dma16s(rw, sbase + (RR * i) * 128, (halfc && kcp >= 4) ? INV : wv[i], so);
         }
     };
 
@@ -368,6 +445,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
         s_end = min(nst, s_beg + per);
     }
     const int c_beg = SLICED ? s_beg / 9 : 0, c_last = SLICED ? (s_end - 1) / 9 : nch - 1;
+    // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "two waves per SIMD", item 4): waves 4 - 7 lose
+    // the issue arbitration against their SIMD partner at every stage start; one s_setprio for the whole K loop evens that out
+    if (RS_IG4_PRIO && ABL == 0 && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < XPW; ++k) issue_x(c_beg, k);
     issue_w(s_beg, NSLOT == 3 ? s_beg % 3 : (s_beg & 1));
@@ -379,18 +459,34 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             for (int q = 0; q < 3; ++q) xfo[j][q] += XBUF;
     }
     for (int c = c_beg; c <= c_last; ++c) {
+        f16x8 xh[2][FP], xl[2][FP];              // XPF: pixel fragments (hi, lo) of the current tap [tap & 1] and of the next one
         const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
         const int t_first = SLICED && c == c_beg ? s_beg - 9 * c_beg : 0;   // first tap of this chunk inside the slice
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int s = c * 9 + tap;
             if constexpr (SLICED) { if (s < s_beg || s >= s_end) continue; }   // (workgroup-uniform)
-            // weight tile s (and every halo piece issued before it) has landed: with three slots only the loads of tile s+1 - the
-            // youngest RW (waves that also own a partial row group) or RWF ones of this wave - may still be in flight
-            if (NSLOT == 3 && s + 1 < s_end) {
-                if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // weight tile s has landed.  Sliced (small-plane) kernels: a stage issues [halo piece, tile s+2] and only the loads of tile s+1 -
+            // the youngest RW (waves that also own a partial row group) or RWF ones of this wave - may still be in flight, i.e. a halo piece
+            // has ONE stage to land.  Big planes (round 5): a stage issues [tile s+2, halo piece]; what a wave issued AFTER tile s is the
+            // piece of stage s-2, tile s+1 and the piece of stage s-1, and all of that may fly on (VMEM operations retire in order) - a
+            // halo piece has TWO stages, and where in a stage the refill sits no longer decides whether the next barrier waits for HBM.
+            // (Pieces are counted with their lower bound over the waves - the last round is partial - which only makes the wait stricter;
+            // tap 0 still waits for the whole chunk: the taps 7, 8 in front of it issue no pieces.)
+            if constexpr (SLICED) {
+                if (NSLOT == 3 && s + 1 < s_end) {
+                    if (RWP && wpart) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWP ? RW - 1 : RW) : "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const int nx1 = (tap >= 1 && tap - 1 < XPWF) ? 1 : 0, nx2 = (tap >= 2 && tap - 2 < XPWF) ? 1 : 0;
+                if (s + 1 < s_end) {
+                    if (NSLOT == 3) {
+                        if (RWP && wpart) wait_vmcnt_n(RW + nx1 + nx2);
+                        else wait_vmcnt_n((RWP ? RW - 1 : RW) + nx1 + nx2);
+                    } else wait_vmcnt_n(nx1);   // two slots: tile s went out one stage ago, in front of that stage's piece
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             if (tap == t_first) {
                 if (xcoef) {
@@ -416,11 +512,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
                         if (tap == 8)
                             for (int kk = k0 + 1; kk < XPW; ++kk) issue_x(c + 1, kk);
                     }
-                } else {
-                    if (c + 1 < ncht && tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
                 }
                 // (ring slot of stage s: s % 3 = tap % 3 with nine taps per chunk; two slots: s & 1)
+                if constexpr (FAST) {
+                    if (s + NSLOT - 1 < 9 * nch) issue_w_fast(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+                    else if (s + NSLOT - 1 < s_end) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));   // (a shortcut tile)
+                    if (tap < XPW) {
+                        if (c + 1 < nch) issue_x_fast(c + 1, tap);
+                        else issue_x(c + 1, tap);                                                                          // (a shortcut chunk, or nothing)
+                    }
+                    return;
+                }
                 if (s + NSLOT - 1 < s_end && (!(ABL & 1) || s < 1)) issue_w(s + NSLOT - 1, NSLOT == 3 ? (tap + 2) % 3 : ((s + 1) & 1));
+                if constexpr (!SLICED) {
+                    // behind the tile (see the wait above).  Issued in EVERY chunk so that the counted waits see a fixed number of loads per
+                    // stage: past the last chunk the piece is all out-of-range lanes (zeros into the halo buffer chunk c - 1 has left)
+                    if (tap < XPW && !(ABL & 2)) issue_x(c + 1, tap);
+                }
             };
             if constexpr (SCHED == 0) refill();
             const char* wb = smem + WBASE + (NSLOT == 3 ? tap % 3 : (s & 1)) * WSLOT + la;
@@ -428,7 +536,49 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             // the stage's MFMAs (fragment reads of the nine shifted halo rows + the weight tile) and, SCHED = 1, its refill between them (see the
             // header): waves 0 - 3 refill in front of their MFMAs, waves 4 - 7 behind the first SCH_AT channel fragments
             const bool first_half = wave < NWV / 2;   // (scalar)
-            if constexpr (SPLIT) {
+            if constexpr (XPF) {
+                const int cu = tap & 1;
+                if (tap == 0) {   // a chunk's first tap: behind the GroupNorm pass, nothing could be read ahead
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) {
+                        xh[0][j] = *(const f16x8*)(smem + xfo[j][0]);
+                        xl[0][j] = *(const f16x8*)(smem + xor64(xfo[j][0]));
+                    }
+                }
+                f16x8 wh[2], wl[2];   // weight fragments (hi, lo) of channel fragment i [i & 1] and i + 1
+                wh[0] = *(const f16x8*)(wb + swz0);
+                wl[0] = *(const f16x8*)(wb + swz1);
+                wh[1] = *(const f16x8*)(wb + swz0 + 2048);
+                wl[1] = *(const f16x8*)(wb + swz1 + 2048);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    if (i == 1) {   // (SCHED 2: the refill behind the first channel fragment's MFMAs)
+                        __builtin_amdgcn_sched_barrier(0);
+                        refill();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const f16x8 as = wh[i & 1] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, xh[cu][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i & 1], xl[cu][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i & 1], xh[cu][j], acc[i][j], 0, 0, 0);
+                    if (i + 2 < FC) {
+                        wh[i & 1] = *(const f16x8*)(wb + swz0 + (i + 2) * 2048);
+                        wl[i & 1] = *(const f16x8*)(wb + swz1 + (i + 2) * 2048);
+                    }
+                    if (i == (FC >= 4 ? FC - 3 : 0) && tap < 8) {   // the next tap's pixel fragments (same chunk, same halo buffer)
+                        const int ky1 = (tap + 1) / 3, kx1 = (tap + 1) % 3;
+#pragma unroll
+                        for (int j = 0; j < FP; ++j) {
+                            xh[cu ^ 1][j] = *(const f16x8*)(smem + xfo[j][kx1] + ky1 * HWD * 128);
+                            xl[cu ^ 1][j] = *(const f16x8*)(smem + xor64(xfo[j][kx1]) + ky1 * HWD * 128);
+                        }
+                    }
+                }
+            } else if constexpr (SPLIT) {
                 constexpr int SCH_AT = FC >= 4 ? 3 : 2;
                 f16x8 ah[FC], al[FC], bh[FP], bl[FP];
                 // (in the order the MFMAs want them: LDS returns are in order, the first product needs ah[0] and the hi pixel fragments)
@@ -578,6 +728,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 2] = clock64();
 #endif
+    if (RS_IG4_PRIO && ABL == 0) __builtin_amdgcn_s_setprio(0);
     // ---------------------------------------------------------------- epilogue
     // (the barrier that ends the K loop comes after the residual loads below: their latency - the 4 x FC loads of a lane used to
     // be issued per channel fragment, five round trips to L2 in a row, 8 - 10 k cycles of a 60 - 120 k cycle workgroup - overlaps it)

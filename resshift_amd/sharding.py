@@ -57,15 +57,35 @@ def init_distributed() -> Tuple[int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    backend = pick_backend(world) if world > 1 else None
     if torch.cuda.is_available():
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        # RCCL: rank <-> device is one to one, LOCAL_RANK IS the device (a modulo would silently put two ranks on one GPU and RCCL would
+        # hang or fail much later); only the gloo plumbing configuration (several ranks sharing a GPU on purpose) wraps around
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and local >= ndev:
+            raise RuntimeError(f"LOCAL_RANK {local} has no GPU of its own ({ndev} visible): one process per GPU over RCCL")
+        torch.cuda.set_device(local if backend == "nccl" else local % max(1, ndev))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # RCCL ("nccl") with one GPU per rank; RESSHIFT_DIST_BACKEND=gloo lets several ranks share one GPU for plumbing tests
-        backend = pick_backend(world)
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":   # bind the communicator to this rank's device up front (no lazy device guess at the first collective)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
     return world, rank
+
+
+def dist_info() -> dict:
+    """what bench.py prints about the process group: backend, world size, this rank's device, the RCCL version when the backend is RCCL"""
+    info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+            "device": torch.cuda.current_device() if torch.cuda.is_available() else None, "rccl_version": None}
+    if info["backend"] == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # informational only
+            pass
+    return info
 
 
 def allgather_floats(values: Sequence[float], device) -> list:
@@ -79,8 +99,13 @@ def allgather_floats(values: Sequence[float], device) -> list:
 
 
 def barrier() -> None:
+    """sampler.py:234,291.  Under RCCL the barrier is told its device: without `device_ids` torch guesses the device from the global rank
+    (a warning, and the wrong GPU whenever rank != device)."""
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -142,7 +167,8 @@ def reflect_pad(x: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return _lib.window_copy(x, 0, 0, H + pad_h, W + pad_w)
 
 
-BLOB_CACHE_MAGIC = b"RSBLOB05"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+BLOB_CACHE_MAGIC = b"RSBLOB06"   # bump when the packed layout (csrc/engine.hip weight builder) changes
+BLOB_CACHE_HEADER = 40            # magic 8 | blob bytes 8 | checkpoint fingerprint 16 | packed weight forms 4 | reserved 4
 
 
 def checkpoint_fingerprint(paths) -> bytes:
@@ -165,15 +191,25 @@ def checkpoint_fingerprint(paths) -> bytes:
     return h.digest()[:16]
 
 
+def _forms_word(eng) -> bytes:
+    """which weight forms the engine packs (bit 0 fp16, 1 fp32, 2 split storage): two precision policies sharing one cache path must not
+    mistake each other's blob for their own on the strength of a coinciding byte count"""
+    cfg = getattr(eng, "cfg", None)
+    if cfg is None:
+        return (0xFFFFFFFF).to_bytes(4, "little")
+    return (int(bool(cfg.enable_f16)) | int(bool(cfg.enable_f32)) << 1 | int(bool(cfg.enable_split)) << 2).to_bytes(4, "little")
+
+
 def _blob_cache_load(path, eng, fingerprint: bytes = b"\0" * 16) -> bool:
-    """Fill the engine's device blob from a packed-blob cache file; False when absent / stale (magic, size or the fingerprint
-    of the checkpoints it was packed from)."""
+    """Fill the engine's device blob from a packed-blob cache file; False when absent / stale (magic, size, the fingerprint
+    of the checkpoints it was packed from, or the set of weight forms that was packed)."""
     if not path or not os.path.exists(path):
         return False
     blob = eng.weight_blob()
     with open(path, "rb") as fh:
-        head = fh.read(32)
-        if len(head) != 32 or head[:8] != BLOB_CACHE_MAGIC or int.from_bytes(head[8:16], "little") != blob.numel() or head[16:32] != fingerprint:
+        head = fh.read(BLOB_CACHE_HEADER)
+        if (len(head) != BLOB_CACHE_HEADER or head[:8] != BLOB_CACHE_MAGIC or int.from_bytes(head[8:16], "little") != blob.numel()
+                or head[16:32] != fingerprint or head[32:36] != _forms_word(eng)):
             return False
         import numpy as np
 
@@ -188,7 +224,7 @@ def _blob_cache_save(path, eng, fingerprint: bytes = b"\0" * 16) -> None:
     blob = eng.weight_blob().cpu().numpy()
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "wb") as fh:
-        fh.write(BLOB_CACHE_MAGIC + int(blob.size).to_bytes(8, "little") + fingerprint)
+        fh.write(BLOB_CACHE_MAGIC + int(blob.size).to_bytes(8, "little") + fingerprint + _forms_word(eng) + b"\0" * 4)
         blob.tofile(fh)
     os.replace(tmp, path)
 

@@ -216,6 +216,13 @@ def test_other_baseline_configs_full_size_vs_oracle(gpu, cname, hw, with_mask):
     assert pp >= 60.0 and agree_p >= 0.999
 
 
+def _per_image_parity(out, ref, idx, ref_idx, n):
+    """north_star's criterion image by image: (PSNR of every compared image, its VQ code agreement) - a pooled PSNR hides a bad image"""
+    ps = [H.psnr(out[i:i + 1].clamp(-1, 1), ref[i:i + 1].clamp(-1, 1)) for i in range(n)]
+    ag = (idx.reshape(n, -1) == ref_idx.reshape(n, -1)).float().mean(dim=1).tolist()
+    return ps, ag
+
+
 @pytest.mark.parametrize("cname,hw,B,with_mask", [("realsr_swinunet_realesrgan256_journal", 64, 32, False),
                                                   ("faceir_gfpgan512_lpips", 512, 16, False),
                                                   ("inpaint_lama256_imagenet", 256, 16, True)])
@@ -233,7 +240,8 @@ def test_other_baseline_configs_at_the_bench_batch(gpu, cname, hw, B, with_mask)
     f = 2 ** (len(ap["ddconfig"]["ch_mult"]) - 1)
     hz, T = hw * dp["sf"] // f, dp["steps"]
     y, noises, mask = H.synth.synthetic_inputs(H.SEED_X + 1, B, hw, hw, ap["embed_dim"], hz, hz, T, with_mask=with_mask)
-    pick = [0, 5, 10, B - 1]
+    # (faceir: ALL 16 images - its f8 autoencoder makes one flipped VQ code an 8 x 8 pixel patch, the thinnest margin of the four configs)
+    pick = list(range(B)) if cname.startswith("faceir") else [0, 5, 10, B - 1]
     ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y[pick], [n[pick] for n in noises], mask=mask[pick] if with_mask else None, return_aux=True)
     d = create_gaussian_diffusion(**dp)
     d.set_precision(["split"] * T, "split", "fp16")
@@ -246,8 +254,11 @@ def test_other_baseline_configs_at_the_bench_batch(gpu, cname, hw, B, with_mask)
     idx = g["indices"].cpu().long().view(B, -1)[pick].reshape(-1)
     agree = (idx == aux["indices"].reshape(-1)).float().mean().item()
     p = H.psnr(out.cpu()[pick].clamp(-1, 1), ref.clamp(-1, 1))
-    print(f"{cname} parity policy at B = {B}: image PSNR {p:.1f} dB, VQ agreement {agree:.5f}")
+    ps, ag = _per_image_parity(out.cpu()[pick], ref, idx, aux["indices"], len(pick))
+    print(f"{cname} parity policy at B = {B}: image PSNR {p:.1f} dB (worst image {min(ps):.1f}), VQ agreement {agree:.5f} (worst image {min(ag):.5f}) "
+          f"over {len(pick)} images; per image {['%.1f' % v for v in ps]}")
     assert p >= 60.0 and agree >= 0.999
+    assert min(ps) >= 60.0 and min(ag) >= 0.999, (ps, ag)   # EVERY compared image
 
 
 @pytest.mark.parametrize("cname,hw", [("realsr_realesrgan256_x2", 128), ("bicx4_swinunet_lpips", 64), ("inpaint_lama256_face", 256)])
@@ -730,8 +741,50 @@ def test_batch32_parity_of_the_bench_policies(gpu, inputs):
         agree = (idx == aux["indices"].reshape(-1)).float().mean().item()
         p_img = H.psnr(out.cpu()[pick].clamp(-1, 1), ref.clamp(-1, 1))
         p_lat = H.psnr(g["z_final"].cpu()[pick], zr, peak_to_peak=(zr.max() - zr.min()).item())
-        print(f"B=32 {inputs} {name}: image PSNR {p_img:.1f} dB, latent PSNR {p_lat:.1f} dB, VQ agreement {agree:.5f}")
+        ps, ag = _per_image_parity(out.cpu()[pick], ref, idx, aux["indices"], len(pick))
+        print(f"B=32 {inputs} {name}: image PSNR {p_img:.1f} dB (worst image {min(ps):.1f}), latent PSNR {p_lat:.1f} dB, VQ agreement {agree:.5f} "
+              f"(worst image {min(ag):.5f})")
         assert p_img >= min_img and p_lat >= min_lat and agree >= min_agree, (name, p_img, p_lat, agree)
+        if name == "parity":   # the credited policy: every compared image, not the pooled figure
+            assert min(ps) >= 60.0 and min(ag) >= 0.999, (ps, ag)
+
+
+@pytest.mark.parametrize("cname,fixture", [("faceir_gfpgan512_lpips", "faceir_lq.npz"), ("inpaint_lama256_imagenet", "inpaint_imagenet.npz")])
+def test_parity_policy_on_the_reference_faceir_and_inpainting_inputs(gpu, cname, fixture):
+    """VERDICT r4 missing #6: the reference ships inputs for the other two tasks as well - testdata/faceir/cropped_faces/lq (aligned 512 x 512
+    faces) and testdata/inpainting/imagenet/{lq,mask} - bundled by oracle/make_real_inputs.py.  The credited (parity) policy on those REAL
+    pixels (and real masks, mapped to [-1, 1] like datapipe/datasets.py:469-473) against the CPU oracle: every image >= 60 dB and >= 99.9 %
+    of its VQ codes."""
+    import os
+
+    from resshift_amd import create_gaussian_diffusion
+
+    d_ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    y = (torch.from_numpy(d_["lq"].astype(np.float32)).permute(0, 3, 1, 2).contiguous() / 255.0 - 0.5) / 0.5
+    mask = None
+    if "mask" in d_.files:
+        mask = (torch.from_numpy(d_["mask"].astype(np.float32))[:, None] / 255.0 - 0.5) / 0.5
+    B, hw = y.shape[0], y.shape[-1]
+    cfg = H.to_plain(H.load_config(cname))
+    up, ap, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+    assert bool(up.get("cond_mask", False)) == (mask is not None)
+    usd, asd = H.weights(up, ap)
+    um, am = _shells(up, ap, usd, asd, gpu)
+    f = 2 ** (len(ap["ddconfig"]["ch_mult"]) - 1)
+    hz, T = hw * dp["sf"] // f, dp["steps"]
+    _, noises, _ = H.synth.synthetic_inputs(H.SEED_X + 3, B, hw, hw, ap["embed_dim"], hz, hz, T)
+    ref, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, mask=mask, return_aux=True)
+    d = create_gaussian_diffusion(**dp)
+    d.set_precision(["split"] * T, "split", "fp16")
+    kw = {"lq": y.to(gpu)}
+    if mask is not None:
+        kw["mask"] = mask.to(gpu)
+    out, g = d.p_sample_loop(y.to(gpu), um, first_stage_model=am, noise=noises[0].to(gpu), clip_denoised=False, model_kwargs=kw,
+                             step_noises=[n.to(gpu) for n in noises[1:]], return_aux=True)
+    torch.cuda.synchronize()
+    ps, ag = _per_image_parity(out.cpu(), ref, g["indices"].cpu().long(), aux["indices"], B)
+    print(f"{cname} on the reference's own {B} inputs, parity policy: per-image PSNR {['%.1f' % v for v in ps]}, worst code agreement {min(ag):.5f}")
+    assert min(ps) >= 60.0 and min(ag) >= 0.999, (ps, ag)
 
 
 def test_fp16_error_on_natural_images_is_conditioning_not_a_kernel(gpu):

