@@ -336,6 +336,11 @@ def main():
             roof["traffic_source"] = f"replayed from {tj['file']} (offline rocprofv3 --pmc of this command on these kernel sources, not observed by this run)"
         else:
             roof["traffic_source"] = why
+        # matrix-pipe utilisation from the SQ counters (SQ_VALU_MFMA_BUSY_CYCLES / SQ_LDS_* per kernel instantiation; scripts/collect_mfma_busy.py),
+        # replayed like the traffic figure: one rocprofv3 --pmc pass of this command on these kernel sources, collected offline
+        mj, mwhy = offline_profile("pmc_mfma_busy", pname, args.config, B)
+        roof["mfma_busy"] = ({"source": f"replayed from {mj['file']} (offline rocprofv3 --pmc of this command on these kernel sources, not observed by this run)",
+                              "family_mfma_busy": mj.get("family_mfma_busy"), "per_kernel": mj.get("per_kernel", [])[:6]} if mj else mwhy)
         if st.get("gn_launches"):
             gbs = st["gn_bytes"] / (st["gn_ms"] * 1e-3) / 1e9 if st["gn_ms"] > 0 else 0.0
             gn = {

@@ -255,7 +255,22 @@ struct IGemmParams {
     const void* sx; const void* sw; const float* sbias;
     int sC, sld;
     unsigned sx_bytes, sw_bytes;   // (filled in by the launcher)
+    // output scatter of the sub-pixel form of "nearest x2 upsample + conv3x3" (engine.hip upfold; models/unet.py:53-81,
+    // ldm/modules/diffusionmodules/model.py:50-65): osc == 2 - this launch is one of four 2x2 convs over the LOW-resolution grid Ho x Wo and
+    // GEMM row (b, oy, ox) is pixel (2 oy + ooy, 2 ox + oox) of the [B][2 Ho][2 Wo] output tensor.  Generic kernels only (igemm / igemm2 /
+    // igemm3 / igemm_split), no residual, no output statistics, no split-K.  osc == 0 / 1: none.
+    int osc, ooy, oox;
 };
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ long long rs_out_m(const IGemmParams& p, long long m) {
+    if (p.osc != 2) return m;
+    const int hw = p.Ho * p.Wo;
+    const int b = (int)(m / hw), r = (int)(m - (long long)b * hw);
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    return ((long long)b * (2 * p.Ho) + 2 * oy + p.ooy) * (2 * p.Wo) + 2 * ox + p.oox;
+}
+#endif
 
 struct DirectConvParams {
     const void* x0; const void* x1;

@@ -171,9 +171,10 @@ struct BasicLayerW { ConvW embed, unembed; std::vector<SwinBlockW> blocks; int C
 struct UBlock {
     bool has_conv = false, has_res = false, has_swin = false, has_down = false, has_up = false;
     ConvW conv; ResBlockW res; BasicLayerW swin; int out_ch = 0; int level = 0;
+    ConvW upf[4]; bool has_upf = false;   // sub-pixel form of the upsampling conv (add_upfold())
 };
 struct AttnW { GNW norm; ConvW q, k, v, proj; int C = 0; };
-struct AELevel { std::vector<ResBlockW> blocks; bool has_resample = false; ConvW resample; };
+struct AELevel { std::vector<ResBlockW> blocks; bool has_resample = false; ConvW resample; ConvW upf[4]; bool has_upf = false; };
 
 struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -547,6 +548,77 @@ struct rs_engine {
         if (has_bias) c.bias = add_f32(prefix + ".bias", Cout);
         return c;
     }
+    // Sub-pixel form of "nearest x2 upsample, then conv3x3" (models/unet.py:53-81 Upsample, ldm/modules/diffusionmodules/model.py:50-65):
+    // every output pixel (2y + py, 2x + px) sees only a 2 x 2 neighbourhood of the LOW-resolution input, because the taps that land on the
+    // same source pixel can be added up front - rows: py = 0: {y - 1: w[0], y: w[1] + w[2]}, py = 1: {y: w[0] + w[1], y + 1: w[2]}, columns
+    // alike; zero padding of the upsampled image IS zero padding of the source (rows -1 and 2H map to -1 and H).  Four 2x2 convs (one per
+    // output parity, pad_t = 1 - py, pad_l = 1 - px) with K = 4 Cin instead of one 3x3 conv with K = 9 Cin on four times the pixels: 2.25 x
+    // fewer multiply-adds, the same result up to the rounding of the summed weights (formed in double from the checkpoint's tensor, like the
+    // other derived matrices).  The generic kernels scatter their rows into the big tensor (IGemmParams::osc).  RS_UPFOLD=0: off.
+    bool add_upfold(const std::string& prefix, int C, ConvW (&upf)[4]) {
+        static const bool on = []() { const char* e = getenv("RS_UPFOLD"); return !(e && e[0] == '0'); }();
+        if (!on || (C % 8)) return false;
+        for (int q = 0; q < 4; ++q) {
+            const int py = q >> 1, px = q & 1;
+            const std::string fk = prefix + ".upfold" + std::to_string(q);
+            derived[fk + ".weight"] = [this, prefix, C, py, px](HostTensor& t) {
+                const HostTensor* w = find(prefix + ".weight");
+                if (!w || w->data.size() != (size_t)C * C * 9) return false;
+                t.data.assign((size_t)C * C * 4, 0.f);
+                t.shape = {C, C, 2, 2};
+                // source offset dy in {0, 1} of parity py collects the taps ky with ((py + ky - 1) >> 1) - (py ? 0 : -1) == dy
+                auto taps = [](int par, int d, int (&k)[2]) -> int {   // taps of one axis that land on source offset d (relative to y - 1 + par)
+                    int n = 0;
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int src = (par + kk - 1) >> 1;            // relative to y (arithmetic shift: -1 >> 1 = -1)
+                        if (src - (par - 1) == d) k[n++] = kk;
+                    }
+                    return n;
+                };
+                for (int co = 0; co < C; ++co)
+                    for (int ci = 0; ci < C; ++ci) {
+                        const float* w9 = w->data.data() + ((size_t)co * C + ci) * 9;
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx) {
+                                int ky[2], kx[2];
+                                const int ny = taps(py, dy, ky), nx = taps(px, dx, kx);
+                                double a = 0.0;
+                                for (int i = 0; i < ny; ++i)
+                                    for (int j = 0; j < nx; ++j) a += (double)w9[ky[i] * 3 + kx[j]];
+                                t.data[((size_t)co * C + ci) * 4 + dy * 2 + dx] = (float)a;
+                            }
+                    }
+                return true;
+            };
+            derived[fk + ".bias"] = [this, prefix, C](HostTensor& t) {
+                const HostTensor* b = find(prefix + ".bias");
+                if (!b || b->data.size() != (size_t)C) return false;
+                t = *b;
+                return true;
+            };
+            upf[q] = add_conv(fk, C, C, 2, 2);
+        }
+        return true;
+    }
+    // the four launches of the sub-pixel form: x [B,H,W,C] -> y [B,2H,2W,C].  Taken when the generic kernels fill the chip without split-K
+    // on the low-resolution grid (the 8 x 8 -> 16 x 16 and 16 x 16 -> 32 x 32 steps at batch 32 do not: they keep the folded-address form).
+    bool upfold_ok(const Exec& ex, const ConvW (&upf)[4], const View& x, const View& y) const {
+        if (ex.dbg || x.dt != y.dt || (x.dt != RS_F16 && x.dt != RS_F16S) || y.H != 2 * x.H || y.W != 2 * x.W || x.C != upf[0].CinP) return false;
+        if (!upf[0].w_for(x.dt)) return false;
+        return rs_igemm_splitk_plan(x.B * x.H * x.W, upf[0].Cout, 4 * x.C, x.dt) == 1 && (long long)x.B * x.H * x.W >= 16384;
+    }
+    void upfold_conv(Exec& ex, const ConvW (&upf)[4], const View& x, const View& y) {
+        if (ex.dry) return;
+        for (int q = 0; q < 4; ++q) {
+            const int py = q >> 1, px = q & 1;
+            View yl = y; yl.H = x.H; yl.W = x.W;   // the launch computes the low-resolution grid; its rows are scattered into y
+            IGemmParams p = conv_params(upf[q], x, nullptr, yl, 1, 1 - py, 1 - px, 1, 0, nullptr, 1.f);
+            p.no_halo = 1;
+            p.osc = 2; p.ooy = py; p.oox = px;
+            if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
+            ex.igemm(p, x.dt, y.dt, 1, "igemm");
+        }
+    }
     // Fragment-major copies of a 1x1 weight [N][K] (N % 16 == 0, K % 32 == 0) for win_attn_qkv_kernel / win_attn_qkv_split_kernel: lane
     // (lr, lg) of the wave that multiplies rows 16 nb .. 16 nb + 15 with k step ks reads W[16 nb + lr][32 ks + 8 lg .. + 7] - from the
     // row-major weight that is 16 different cache lines per wave instruction, from this copy 8 full ones.
@@ -748,7 +820,8 @@ struct rs_engine {
                 if (in_attn_res(ds) && i == 0) { b.has_swin = true; b.swin = add_basiclayer(p + "." + std::to_string(sub++), ch, ds); }
                 if (level && i == u.num_res_blocks[level]) {
                     b.has_up = true;
-                    b.conv = add_conv(p + "." + std::to_string(sub++) + ".conv", ch, ch, 3, 3);
+                    b.conv = add_conv(p + "." + std::to_string(sub) + ".conv", ch, ch, 3, 3);
+                    b.has_upf = add_upfold(p + "." + std::to_string(sub++) + ".conv", ch, b.upf);
                     ds *= 2;
                 }
                 b.out_ch = ch;
@@ -821,6 +894,7 @@ struct rs_engine {
             if (l != 0) {
                 L.has_resample = true;
                 L.resample = add_conv("decoder.up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3, 3);
+                L.has_upf = add_upfold("decoder.up." + std::to_string(l) + ".upsample.conv", block_in, L.upf);
             }
             dec_levels[l] = L;
         }
@@ -1153,18 +1227,14 @@ struct rs_engine {
             // partial set per window; MLP -> the next block's norm1: one per 128-token tile) and - round 4 - the launch that completes an
             // image's statistics writes that GroupNorm's coefficients (tail): no pass over those tensors, no coefficient launch.
             //   split storage: default on (RS_GN_SWIN_STATS_SPLIT=0: statistics pass + tail as for any tensor without producer statistics);
-            //   fp16 storage: RS_GN_SWIN_STATS=1 keeps the round-3 form (statistics only, coefficient kernel; measured slower than the passes
-            //   it removes, profiles/r3_negative_results.txt) - default off.
-            static const bool swin_stats = []() { const char* v = getenv("RS_GN_SWIN_STATS"); return v && v[0] == '1'; }();
+            //   fp16 storage: never (round 3's form - statistics only, coefficient kernel - measured slower than the passes it removes,
+            //   profiles/r3_negative_results.txt; its knob left the tree in round 5).
             static const bool swin_stats_split = []() { const char* v = getenv("RS_GN_SWIN_STATS_SPLIT"); return !(v && v[0] == '0'); }();
             const bool sstats = X.dt == RS_F16S && swin_stats_split && !ex.dbg;
             if (fuse_proj && sstats && fold2) {   // (only where norm2 is a coefficient-only GroupNorm: the fused MLP applies it)
                 e2.stS = (X.H / 8) * (X.W / 8); e2.stld = E;
                 e2.st = ex.pool((size_t)X.B * e2.stS * e2.stld * 2 * sizeof(float));
                 e2.st_prod = ex.prod_seq++;
-            } else if (fuse_proj && X.dt == RS_F16 && swin_stats && !ex.dbg) {
-                e2.stS = (X.H / 8) * (X.W / 8); e2.stld = e2.ld;
-                e2.st = (float*)ex.raw((size_t)X.B * e2.stS * e2.stld * 2 * sizeof(float));
             }
             if (fuse_qkv) {
                 if (!ex.dry) {
@@ -1224,9 +1294,6 @@ struct rs_engine {
                     e3.stS = HWt / 128; e3.stld = E;
                     e3.st = ex.pool((size_t)X.B * e3.stS * e3.stld * 2 * sizeof(float));
                     e3.st_prod = ex.prod_seq++;
-                } else if (X.dt == RS_F16 && swin_stats && !ex.dbg && HWt % 32 == 0 && Mtok % 32 == 0) {   // consumed by the next block's norm1 (if any)
-                    e3.stS = HWt / 32; e3.stld = e3.ld;
-                    e3.st = (float*)ex.raw((size_t)X.B * e3.stS * e3.stld * 2 * sizeof(float));
                 }
                 if (!ex.dry) {
                     const void* w1 = s.fc1.w_for(X.dt); const void* w2 = s.fc2.w_for(X.dt);
@@ -1490,8 +1557,13 @@ struct rs_engine {
                     }
                 }
                 if (b.has_up) {
-                    want_stats(ex, b.conv, cur, y, nullptr, 1, 1, 2);
-                    conv(ex, b.conv, cur, nullptr, y, 1, 1, 1, 2, 0, nullptr);  // nearest x2 folded into the conv
+                    if (b.has_upf && upfold_ok(ex, b.upf, cur, y)) {
+                        y.st = nullptr; y.st2 = nullptr; y.st_prod = -1;      // (four launches: the consumer's GroupNorm takes its statistics pass)
+                        upfold_conv(ex, b.upf, cur, y);
+                    } else {
+                        want_stats(ex, b.conv, cur, y, nullptr, 1, 1, 2);
+                        conv(ex, b.conv, cur, nullptr, y, 1, 1, 1, 2, 0, nullptr);  // nearest x2 folded into the conv's addressing
+                    }
                 }
             }
             if (j + 1 < n_out) note(cat_lo[j + 1], y); else last = y;
@@ -1590,7 +1662,8 @@ struct rs_engine {
             }
             if (L.has_resample) {
                 View y = ex.T(B, h.H * 2, h.W * 2, h.C, dt);
-                conv(ex, L.resample, h, nullptr, y, 1, 1, 1, 2, 0, nullptr);
+                if (L.has_upf && upfold_ok(ex, L.upf, h, y)) upfold_conv(ex, L.upf, h, y);
+                else conv(ex, L.resample, h, nullptr, y, 1, 1, 1, 2, 0, nullptr);
                 h = y;
             }
         }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             const int n = n0 + wc * (BC / 2) + c8 * 8;
             if (m >= p.M || n >= p.Cout) continue;
             const uint4 v = *(const uint4*)(stg + row * ROWB + c8 * 16);
-            TO* yp = y + (long long)m * p.ldy + n;
+            TO* yp = y + rs_out_m(p, m) * p.ldy + n;
             if (vec_ok && n + 7 < p.Cout) {
                 *(uint4*)yp = v;
             } else {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
                     if (p.bias && n + r < p.Cout) t += p.bias[n + r];
                     v[r] = epi_act<TO>(t, p.act);
                 }
-                TO* yp = y + (long long)m * p.ldy + n;
+                TO* yp = y + rs_out_m(p, m) * p.ldy + n;
                 if (n + 3 < p.Cout && vec_ok && (!res || res_vec)) {
                     if (res) {
                         float rv[4];
@@ -422,6 +422,9 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     if (p.up != 1 && p.up != 2) return -2;
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
+    // scattered rows (sub-pixel form of an upsampling conv, IGemmParams::osc): plain single launches only - the residual, the output
+    // statistics and the split-K slabs are all indexed by the GEMM row
+    if (p.osc != 0 && p.osc != 1 && (p.osc != 2 || p.res || p.ystats || p.tail.coef || p.splitk > 1 || nz != 1 || p.up != 1 || p.stride != 1 || p.C1 != 0)) return -2;
     {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
         int tw4 = 0, bc4 = 0;
         if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, in_dt, tw4, bc4, st);

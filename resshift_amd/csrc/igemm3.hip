@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void igemm3_kernel(IGemmParams p) {
             const int n = n0 + wc * (BC / 2) + c8 * 8;
             if (m >= p.M || n >= p.Cout) continue;
             const uint4 v = *(const uint4*)(stg + row * ROWB + c8 * 16);
-            TO* yp = y + (long long)m * p.ldy + n;
+            TO* yp = y + rs_out_m(p, m) * p.ldy + n;
             if (vec_ok && n + 7 < p.Cout) {
                 *(uint4*)yp = v;
             } else {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void igemm3_kernel(IGemmParams p) {
                     if (p.bias && n + r < p.Cout) t += p.bias[n + r];
                     v[r] = epi_act<TO>(t, p.act);
                 }
-                TO* yp = y + (long long)m * p.ldy + n;
+                TO* yp = y + rs_out_m(p, m) * p.ldy + n;
                 if (vec_ok && (!res || res_vec)) {
                     if (res) {
                         float rv[4];

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
     if (nk > 0) issue(0);
     if (nk > 1) issue(1);
     if constexpr (!PIPE) {
-        // reference schedule (RS_SPLIT_PIPE=0, for A/B runs): the whole refill is issued right behind the barrier
+        // reference schedule (round 2's A/B partner, not instantiated any more): the whole refill is issued right behind the barrier
         for (int kt = 0; kt < nk; ++kt) {
             if (kt == 0 && nk > 1) {   // stage 1 was issued with stage 0; its loads (two fewer on the waves that skip the partial round) may fly on
                 if (RWP && !wpart) wait_vmcnt<L - 2>(); else wait_vmcnt<L>();
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             const int n = n0 + wc * (BC / 2) + c8 * 8;
             if (m >= p.M || n >= p.Cout) continue;
             const uint4 v = *(const uint4*)(stg + half * WTILE + row * ROWB + c8 * 16);
-            f16* yp = y + (long long)m * p.ldy * 2 + half * p.ldy + n;
+            f16* yp = y + rs_out_m(p, m) * p.ldy * 2 + half * p.ldy + n;
             if (vec_ok && n + 7 < p.Cout) {
                 *(uint4*)yp = v;
             } else {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
             for (int i = 0; i < FC; ++i) {
                 const int n = n0 + wc * (BC / 2) + i * 16 + lg * 4;
                 if (m >= p.M || n >= p.Cout) continue;
-                float* yp = y + (long long)m * p.ldy + n;
+                float* yp = y + rs_out_m(p, m) * p.ldy + n;
                 if (n + 3 < p.Cout && vec_ok) *(f32x4*)yp = am[i][j];
                 else for (int r = 0; r < 4 && n + r < p.Cout; ++r) yp[r] = am[i][j][r];
             }
@@ -546,7 +546,6 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
 
 template <typename TO, int BP, int BC, int NWV>
 hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
-    static const bool pipe = []() { const char* e = getenv("RS_SPLIT_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
 #ifdef RS_SPLIT_ABLATE
     if constexpr (std::is_same<TO, h2s>::value && NWV == 8) {
         static const int abl = []() { const char* e = getenv("RS_IGEMM_DBG"); return e ? atoi(e) : 0; }();
@@ -559,7 +558,7 @@ hipError_t launch_cfg(const IGemmParams& p, int nz, hipStream_t st) {
         }
     }
 #endif
-    return pipe ? launch_cfg2<TO, BP, BC, NWV, true>(p, nz, st) : launch_cfg2<TO, BP, BC, NWV, false>(p, nz, st);
+    return launch_cfg2<TO, BP, BC, NWV, true>(p, nz, st);   // (the un-pipelined reference schedule, PIPE = false, is no longer instantiated)
 }
 
 template <typename TO>
@@ -570,15 +569,6 @@ hipError_t launch_t(const IGemmParams& p, int BP, int BC, int nz, hipStream_t st
             case 160: return launch_cfg<TO, 64, 160, 4>(p, nz, st);
             case 192: return launch_cfg<TO, 64, 192, 4>(p, nz, st);
             default: return launch_cfg<TO, 64, 128, 4>(p, nz, st);
-        }
-    }
-    static const bool w4 = []() { const char* e = getenv("RS_SPLIT_W4"); return e && e[0] == '1'; }();   // A/B knob: 4 waves of 64 x BC/2
-    if (w4) {
-        switch (BC) {
-            case 64: break;
-            case 160: return launch_cfg<TO, 128, 160, 4>(p, nz, st);
-            case 192: return launch_cfg<TO, 128, 192, 4>(p, nz, st);
-            default: return launch_cfg<TO, 128, 128, 4>(p, nz, st);
         }
     }
     switch (BC) {

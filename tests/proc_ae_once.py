@@ -27,7 +27,7 @@ g = torch.Generator().manual_seed(side)
 img = (torch.rand(1, 3, side, side, generator=g) * 2 - 1).to(dev)
 z = am.encode(img, prec=prec)
 res = {"z": z.cpu()}
-if which == "tiny":
+if which == "tiny" or os.environ.get("RS_TEST_DECODE"):
     res["img"] = am.decode(z, prec=prec).cpu()
 torch.cuda.synchronize()
 torch.save(res, out)

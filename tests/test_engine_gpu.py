@@ -690,6 +690,42 @@ def test_patch_unembed_fold_matches_the_separate_conv(gpu, tmp_path):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["split", "fp16"])
+def test_upsample_subpixel_form_matches_the_folded_address_conv(gpu, tmp_path, prec):
+    """Round 5: `Upsample` (models/unet.py:53-81; ldm/modules/diffusionmodules/model.py:50-65: nearest x2, then conv3x3) as four 2x2 convs
+    over the low-resolution grid with the taps that fall on one source pixel summed up front (engine.hip add_upfold: 2.25 x fewer
+    multiply-adds) against RS_UPFOLD=0, the 3x3 conv whose addressing folds the upsample: a full-size UNet forward at the bench batch (the
+    32 x 32 -> 64 x 64 step takes the new form there) and the VQ-f4 decoder of a 512 x 512 image (both of its steps), same weights, same
+    inputs.  fp32-class agreement in split storage; fp16 storage rounds the SUMMED weight once instead of every tap - fp16-class agreement."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def unet(tag, **env):
+        out = tmp_path / f"u_{tag}.pt"
+        e = dict(os.environ, RS_TEST_META="1", RS_TEST_PREC=prec, RS_TEST_B="32", **{k: str(v) for k, v in env.items()})
+        subprocess.run([sys.executable, os.path.join(here, "proc_unet_once.py"), str(out)], check=True, env=e, timeout=600)
+        return torch.load(out)
+
+    def ae(tag, **env):
+        out = tmp_path / f"a_{tag}.pt"
+        e = dict(os.environ, RS_TEST_DECODE="1", **{k: str(v) for k, v in env.items()})
+        subprocess.run([sys.executable, os.path.join(here, "proc_ae_once.py"), str(out), "realsr", "512", prec], check=True, env=e, timeout=600)
+        return torch.load(out)
+
+    tol = 2e-5 if prec == "split" else 2e-2
+    fu, pu = unet("fold"), unet("plain", RS_UPFOLD=0)
+    assert torch.isfinite(fu["out"]).all() and torch.equal(fu["out"], fu["out2"])
+    eu = H.rel_err(fu["out"], pu["out"])
+    fa, pa = ae("fold"), ae("plain", RS_UPFOLD=0)
+    ea = H.rel_err(fa["img"], pa["img"])
+    print(f"sub-pixel upsample ({prec}): UNet launches {pu['launches']} -> {fu['launches']}, max error / max|out| {eu:.2e}; decoder {ea:.2e}")
+    assert fu["launches"] > pu["launches"]          # the new form is in use at this batch (3 more conv launches + the GroupNorm's statistics pass)
+    assert eu < tol and ea < tol
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 2: parity at the headline batch size, the precision policies the bench reports, real pixels, forced VQ indices,
 # timestep respacing.

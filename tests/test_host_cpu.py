@@ -473,7 +473,8 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     assert v[0] > 0 and v[1] > 0          # tails were planned at all
     if cname.startswith("realsr") and B == 32 and prec == 2:
         # (round 5: 2 592 with the three folds; + 210 split-K reduce launches of the 16 x 16 level's 128-pixel tiles, measured 2.1 ms FASTER)
-        assert v[8] <= 2810, v[8]
+        # (+ 66: the sub-pixel form of the three large upsampling convs is four launches each, and the UNet's costs its consumer a statistics pass)
+        assert v[8] <= 2880, v[8]
         # the shortcut fold: 7 ResBlocks per UNet forward x 15 steps + the encoder's two run their 1x1 shortcut inside conv2
         r0 = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "_fake_device_plumbing.py"), cname, str(B), str(prec)],
                             env=dict(env, RS_SKIP_FOLD="0"), capture_output=True, text=True, timeout=600)
