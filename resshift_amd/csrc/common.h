@@ -258,7 +258,8 @@ struct IGemmParams {
     // output scatter of the sub-pixel form of "nearest x2 upsample + conv3x3" (engine.hip upfold; models/unet.py:53-81,
     // ldm/modules/diffusionmodules/model.py:50-65): osc == 2 - this launch is one of four 2x2 convs over the LOW-resolution grid Ho x Wo and
     // GEMM row (b, oy, ox) is pixel (2 oy + ooy, 2 ox + oox) of the [B][2 Ho][2 Wo] output tensor.  Generic kernels only (igemm / igemm2 /
-    // igemm3 / igemm_split), no residual, no output statistics, no split-K.  osc == 0 / 1: none.
+    // igemm3 / igemm_split), no residual, no split-K; output statistics from igemm_split only (the four launches fill ONE slab array -
+    // an image's slabs are class 0's tiles, then class 1's, ... - and share the GroupNorm tail's ticket).  osc == 0 / 1: none.
     int osc, ooy, oox;
 };
 

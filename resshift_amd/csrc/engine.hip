@@ -600,21 +600,41 @@ struct rs_engine {
         }
         return true;
     }
-    // the four launches of the sub-pixel form: x [B,H,W,C] -> y [B,2H,2W,C].  Taken when the generic kernels fill the chip without split-K
-    // on the low-resolution grid (the 8 x 8 -> 16 x 16 and 16 x 16 -> 32 x 32 steps at batch 32 do not: they keep the folded-address form).
+    // the four launches of the sub-pixel form: x [B,H,W,C] -> y [B,2H,2W,C].  Taken when the low-resolution grid alone fills the chip
+    // (the 8 x 8 -> 16 x 16 and 16 x 16 -> 32 x 32 steps at batch 32 do not: they keep the folded-address form).
     bool upfold_ok(const Exec& ex, const ConvW (&upf)[4], const View& x, const View& y) const {
         if (ex.dbg || x.dt != y.dt || (x.dt != RS_F16 && x.dt != RS_F16S) || y.H != 2 * x.H || y.W != 2 * x.W || x.C != upf[0].CinP) return false;
         if (!upf[0].w_for(x.dt)) return false;
-        return rs_igemm_splitk_plan(x.B * x.H * x.W, upf[0].Cout, 4 * x.C, x.dt) == 1 && (long long)x.B * x.H * x.W >= 16384;
+        // (measured, profiles/r5_upfold_ab.txt: with the 16 -> 32 and 8 -> 16 steps as well - 8192 / 2048 low-resolution pixels at batch 32, four
+        // launches that cannot fill the chip each - the pass is 0.9 ms slower than with the 32 -> 64 step alone)
+        return (long long)x.B * x.H * x.W >= 16384;
+    }
+    // statistics of y for the consuming GroupNorm from the four launches' epilogues (split storage): one slab per low-resolution pixel tile
+    // and parity class
+    void upfold_want_stats(Exec& ex, const ConvW (&upf)[4], const View& x, View& y) {
+        static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
+        static const bool gen = []() { const char* e = getenv("RS_GN_GEN_STATS"); return !(e && e[0] == '0'); }();
+        y.st = nullptr; y.st2 = nullptr; y.st_prod = -1;
+        if (!on || !gen || ex.dbg || x.dt != RS_F16S || y.dt != RS_F16S) return;
+        View yl = y; yl.H = x.H; yl.W = x.W;
+        const IGemmParams pp = conv_params(upf[0], x, nullptr, yl, 1, 1, 1, 1, 0, nullptr, 1.f);
+        const int spx = rs_igemm_split_stats_px(&pp, 1);
+        if (spx <= 0 || ((x.H * x.W) % spx)) return;
+        y.stS = 4 * (x.H * x.W / spx); y.stld = y.C;
+        y.st = ex.pool((size_t)y.B * y.stS * y.stld * 2 * sizeof(float));
+        y.st_prod = ex.prod_seq++;
     }
     void upfold_conv(Exec& ex, const ConvW (&upf)[4], const View& x, const View& y) {
         if (ex.dry) return;
+        GNTail tl{};
+        if (y.st) (void)ex.fill_tail(y.st_prod, y.B, tl);   // ONE tail (one ticket per image) for the four launches
         for (int q = 0; q < 4; ++q) {
             const int py = q >> 1, px = q & 1;
             View yl = y; yl.H = x.H; yl.W = x.W;   // the launch computes the low-resolution grid; its rows are scattered into y
             IGemmParams p = conv_params(upf[q], x, nullptr, yl, 1, 1 - py, 1 - px, 1, 0, nullptr, 1.f);
             p.no_halo = 1;
             p.osc = 2; p.ooy = py; p.oox = px;
+            if (y.st) { p.ystats = y.st; p.ystats_ld = y.stld; p.tail = tl; }
             if (!p.w) { ex.err = -3; g_err = "weights for this precision were not packed (enable_f16/enable_f32/enable_split)"; return; }
             ex.igemm(p, x.dt, y.dt, 1, "igemm");
         }
@@ -1558,7 +1578,7 @@ struct rs_engine {
                 }
                 if (b.has_up) {
                     if (b.has_upf && upfold_ok(ex, b.upf, cur, y)) {
-                        y.st = nullptr; y.st2 = nullptr; y.st_prod = -1;      // (four launches: the consumer's GroupNorm takes its statistics pass)
+                        upfold_want_stats(ex, b.upf, cur, y);
                         upfold_conv(ex, b.upf, cur, y);
                     } else {
                         want_stats(ex, b.conv, cur, y, nullptr, 1, 1, 2);

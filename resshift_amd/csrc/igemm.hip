@@ -424,7 +424,8 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     if (p.splitk > 1 && (nz != 1 || !p.partial || (p.Cout & 3))) return -2;
     // scattered rows (sub-pixel form of an upsampling conv, IGemmParams::osc): plain single launches only - the residual, the output
     // statistics and the split-K slabs are all indexed by the GEMM row
-    if (p.osc != 0 && p.osc != 1 && (p.osc != 2 || p.res || p.ystats || p.tail.coef || p.splitk > 1 || nz != 1 || p.up != 1 || p.stride != 1 || p.C1 != 0)) return -2;
+    // (output statistics: the split-storage kernel only - its four launches fill one slab array and share the GroupNorm tail's ticket)
+    if (p.osc != 0 && p.osc != 1 && (p.osc != 2 || p.res || (p.ystats && in_dt != RS_F16S) || p.splitk > 1 || nz != 1 || p.up != 1 || p.stride != 1 || p.C1 != 0)) return -2;
     {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
         int tw4 = 0, bc4 = 0;
         if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, in_dt, tw4, bc4, st);

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     constexpr int NXB = 2;                        // halo buffers
     constexpr int LDSCAP = 160 * 1024;
     // Measured (profiles/r5_halo_refill_ab.txt, scripts/igemm_bench.py, conv layer mix of one pass): split storage 152.2 ms (round 4) ->
-    // 144.9 with SCHED 2 (SCHED 1: 152.7 - its late refills leave a wave's weight tile less than a stage to land); fp16 66.9 -> 62.8 with
-    // SCHED 1 (SCHED 2: 64.1).  Default: 2 for split storage, 1 for fp16.  -DRS_IG4_SCHED=n forces one form (A/B builds).
+    // 144.9 with SCHED 2 (SCHED 1: 152.7, SCHED 0 on the same sources: 147.8); fp16 66.9 -> 62.8 with SCHED 1 (SCHED 2: 64.1, SCHED 0: 66.3).
+    // Default: 2 for split storage, 1 for fp16.  -DRS_IG4_SCHED=n forces one form (A/B builds).
 #ifdef RS_IG4_SCHED
     constexpr int SCHED = (ABL == 0) ? RS_IG4_SCHED : 0;
 #else
@@ -110,17 +110,11 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
 #ifndef RS_IG4_FAST
 #define RS_IG4_FAST 1
 #endif
-#ifndef RS_IG4_PRIO
-#define RS_IG4_PRIO 1
-#endif
-    // XPF (round 5, split storage, big planes): the pixel fragments of tap t + 1 are read from the halo buffer while tap t's last MFMAs
-    // run - the halo chunk is complete and untouched for all nine taps, only the WEIGHT tile is what a stage's barrier waits for - and
-    // the weight fragments are read one channel fragment ahead instead of all at once.  Behind a barrier the first MFMA then waits for
-    // one weight fragment instead of nine reads of an LDS that all eight waves hit together (and the fragment registers stay at 84).
-#ifndef RS_IG4_XPF
-#define RS_IG4_XPF 1
-#endif
-    constexpr bool XPF = SPLIT && SEG == 0 && ABL == 0 && RS_IG4_XPF;
+    // (Round 5 also measured, on these sources, and dropped: the NEXT tap's pixel fragments read from the halo buffer during the current tap's
+    // last MFMAs with the weight fragments one channel fragment ahead - behind a barrier the first MFMA waits for one read instead of
+    // nine - : 146.4 -> 144.9 ms on the conv layer mix of the microbenchmark, 109.88 vs 109.86 ms of the family in the pass; and s_setprio 1
+    // for waves 4 - 7 over the K loop: 110.1 vs 109.9 ms.  profiles/r5_halo_refill_ab.txt.  Neither start-of-stage latency is what a stage
+    // waits for.)
     // FAST (round 5): the refill's per-lane byte offsets - XPW halo pieces and RW weight row groups of this wave - are computed ONCE and
     // kept in registers (10 VGPRs); what changes from stage to stage (chunk, tap) is a scalar and travels in the buffer instruction's
     // SGPR offset.  A stage's refill shrinks from ~100 instructions (pixel decode, bounds tests, 32-bit multiplies, per piece and row
@@ -445,9 +439,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
         s_end = min(nst, s_beg + per);
     }
     const int c_beg = SLICED ? s_beg / 9 : 0, c_last = SLICED ? (s_end - 1) / 9 : nch - 1;
-    // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "two waves per SIMD", item 4): waves 4 - 7 lose
-    // the issue arbitration against their SIMD partner at every stage start; one s_setprio for the whole K loop evens that out
-    if (RS_IG4_PRIO && ABL == 0 && wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < XPW; ++k) issue_x(c_beg, k);
     issue_w(s_beg, NSLOT == 3 ? s_beg % 3 : (s_beg & 1));
@@ -459,7 +450,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             for (int q = 0; q < 3; ++q) xfo[j][q] += XBUF;
     }
     for (int c = c_beg; c <= c_last; ++c) {
-        f16x8 xh[2][FP], xl[2][FP];              // XPF: pixel fragments (hi, lo) of the current tap [tap & 1] and of the next one
         const bool two = c * 64 + 64 <= Cin;     // fp16: full chunk = two k-steps of 32 channels (half chunk: one)
         const int t_first = SLICED && c == c_beg ? s_beg - 9 * c_beg : 0;   // first tap of this chunk inside the slice
 #pragma unroll
@@ -536,49 +526,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
             // the stage's MFMAs (fragment reads of the nine shifted halo rows + the weight tile) and, SCHED = 1, its refill between them (see the
             // header): waves 0 - 3 refill in front of their MFMAs, waves 4 - 7 behind the first SCH_AT channel fragments
             const bool first_half = wave < NWV / 2;   // (scalar)
-            if constexpr (XPF) {
-                const int cu = tap & 1;
-                if (tap == 0) {   // a chunk's first tap: behind the GroupNorm pass, nothing could be read ahead
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) {
-                        xh[0][j] = *(const f16x8*)(smem + xfo[j][0]);
-                        xl[0][j] = *(const f16x8*)(smem + xor64(xfo[j][0]));
-                    }
-                }
-                f16x8 wh[2], wl[2];   // weight fragments (hi, lo) of channel fragment i [i & 1] and i + 1
-                wh[0] = *(const f16x8*)(wb + swz0);
-                wl[0] = *(const f16x8*)(wb + swz1);
-                wh[1] = *(const f16x8*)(wb + swz0 + 2048);
-                wl[1] = *(const f16x8*)(wb + swz1 + 2048);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    if (i == 1) {   // (SCHED 2: the refill behind the first channel fragment's MFMAs)
-                        __builtin_amdgcn_sched_barrier(0);
-                        refill();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const f16x8 as = wh[i & 1] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|w| < 32)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, xh[cu][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i & 1], xl[cu][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i & 1], xh[cu][j], acc[i][j], 0, 0, 0);
-                    if (i + 2 < FC) {
-                        wh[i & 1] = *(const f16x8*)(wb + swz0 + (i + 2) * 2048);
-                        wl[i & 1] = *(const f16x8*)(wb + swz1 + (i + 2) * 2048);
-                    }
-                    if (i == (FC >= 4 ? FC - 3 : 0) && tap < 8) {   // the next tap's pixel fragments (same chunk, same halo buffer)
-                        const int ky1 = (tap + 1) / 3, kx1 = (tap + 1) % 3;
-#pragma unroll
-                        for (int j = 0; j < FP; ++j) {
-                            xh[cu ^ 1][j] = *(const f16x8*)(smem + xfo[j][kx1] + ky1 * HWD * 128);
-                            xl[cu ^ 1][j] = *(const f16x8*)(smem + xor64(xfo[j][kx1]) + ky1 * HWD * 128);
-                        }
-                    }
-                }
-            } else if constexpr (SPLIT) {
+            if constexpr (SPLIT) {
                 constexpr int SCH_AT = FC >= 4 ? 3 : 2;
                 f16x8 ah[FC], al[FC], bh[FP], bl[FP];
                 // (in the order the MFMAs want them: LDS returns are in order, the first product needs ah[0] and the hi pixel fragments)
@@ -728,7 +676,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
 #if defined(RS_SPLIT_ABLATE) && defined(RS_IGEMM4_MAIN_TU)
     if (tid == 0 && blockIdx.x < 8192) g_ig4_clk[4 * blockIdx.x + 2] = clock64();
 #endif
-    if (RS_IG4_PRIO && ABL == 0) __builtin_amdgcn_s_setprio(0);
     // ---------------------------------------------------------------- epilogue
     // (the barrier that ends the K loop comes after the residual loads below: their latency - the 4 x FC loads of a lane used to
     // be issued per channel fragment, five round trips to L2 in a row, 8 - 10 k cycles of a 60 - 120 k cycle workgroup - overlaps it)

@@ -430,7 +430,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void igemm_split_kernel
                     float a = 0.f, q = 0.f;
 #pragma unroll
                     for (int w4 = 0; w4 < WPN; ++w4) { a += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2]; q += sb[((hw_ * WPN + w4) * (BC / 2) + cl) * 2 + 1]; }
-                    float* dst = p.ystats + (((long long)tail_img * (hw / BP) + (m0 - tail_img * hw) / BP) * p.ystats_ld + n0 + c) * 2;
+                    // (osc == 2: this launch is parity class 2 ooy + oox of four; an image's slabs are the four classes' tiles one after the other)
+                    const long long slab = p.osc == 2 ? ((long long)tail_img * 4 + 2 * p.ooy + p.oox) * (hw / BP) + (m0 - tail_img * hw) / BP
+                                                      : (long long)tail_img * (hw / BP) + (m0 - tail_img * hw) / BP;
+                    float* dst = p.ystats + (slab * p.ystats_ld + n0 + c) * 2;
                     if (p.tail.coef) rs_pub_pair(dst, a, q);
                     else { dst[0] = a; dst[1] = q; }
                 }
@@ -530,8 +533,9 @@ hipError_t launch_cfg2(IGemmParams p, int nz, hipStream_t st) {
             if ((p.M % BP) || (hw % BP)) return hipErrorInvalidValue;   // whole tiles inside one image (rs_igemm_split_stats_px)
             if (p.tail.coef) {
                 if (p.tail.C > 2048 || p.tail.groups < 1 || p.tail.groups > 64 || (p.tail.C % p.tail.groups)) return hipErrorInvalidValue;   // (the finish's LDS scratch: 2 C + 2 groups floats)
-                p.tail.expected = (hw / BP) * ((p.Cout + BC - 1) / BC);
-                p.tail.st0 = p.ystats; p.tail.S0 = hw / BP; p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
+                const int classes = p.osc == 2 ? 4 : 1;   // (scattered launches: the four parity classes share one ticket and one slab array)
+                p.tail.expected = classes * (hw / BP) * ((p.Cout + BC - 1) / BC);
+                p.tail.st0 = p.ystats; p.tail.S0 = classes * (hw / BP); p.tail.ld0 = p.ystats_ld; p.tail.n0 = p.Cout;
             }
         }
     }
