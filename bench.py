@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("RESSHIFT_PRECISION", PARITY_POLICY),
                     help="the policy the whole line describes (default: parity = the fastest policy that meets the 60 dB tolerance)")
     ap.add_argument("--parity-images", type=int, default=32, help="images of the batch compared with the CPU oracle (chunks of 8)")
-    ap.add_argument("--cpu-seconds", type=float, default=240.0, help="budget of CPU-oracle time: further chunks of 8 images are skipped once it is spent")
+    ap.add_argument("--cpu-seconds", type=float, default=200.0, help="budget of CPU-oracle time: further chunks of 8 images are skipped once it is spent")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle (no cpu_baseline / parity legs)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary policies (fp16 / parity beside the headline)")

@@ -167,6 +167,8 @@ extern "C" int rs_igemm4_plan(const IGemmParams* pp, int in_dt, int out_dt, int 
     // 4 x 64 tiles on planes that allow them, except for the 160-channel tile: 8 x 32 leaves room for the third weight slot
     int tw = (p.Wo % 64 == 0) ? 64 : 32;
     if (best == 160 && (p.Wo % 32 == 0) && (p.Ho % 8 == 0)) tw = 32;
+    // (round 5: 8 x 32 tiles - halo overlap 1.33 x instead of 1.55 x - for the 128-channel tile as well: 65.6 -> 64.8 ms / 27.3 -> 27.0 ms on the
+    // autoencoder's conv mix in the microbenchmark, 241.3 - 241.9 vs 240.9 - 241.3 ms in the pass: within noise, not taken; profiles/r5_negative_results.txt)
     const int th = 256 / tw;
     if ((p.Wo % tw) || (p.Ho % th)) return 0;
     if (p.Cout < 96 || (in_dt == RS_F16S && best == 192)) return 0;   // (split, BC = 192: over the register budget; no 3x3 conv of the models needs it)

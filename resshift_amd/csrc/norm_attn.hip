@@ -344,7 +344,9 @@ extern "C" int rs_groupnorm_launch(const GNParams* pp, int dt, int apply_slabs, 
     const size_t lds = (2 * p.C + 2 * p.groups + 2 * 256) * sizeof(float);
     const bool need_stats = p.cpartial == nullptr;   // (else the producing conv's epilogue already left per-channel partial sums)
     static const bool tail_on = []() { const char* e = getenv("RS_GN_TAIL"); return !(e && e[0] == '0'); }();
-    const bool use_tail = tail_on && need_stats && p.coef && p.ticket;
+    // (the tail's finish works in gn_stats_kernel's red[256][17] array: 2 C + 2 groups floats below the flag word at red[255][16], a slice
+    // tree of 256 / groups lanes per group - ADVICE r4: enforce what the engine's groups = 32 satisfies by construction)
+    const bool use_tail = tail_on && need_stats && p.coef && p.ticket && 2 * p.C + 2 * p.groups <= 4351 && p.groups > 0 && (256 % p.groups) == 0;
     if (use_tail) {
         tail.gamma = p.gamma; tail.beta = p.beta; tail.film = p.film; tail.coef = p.coef; tail.ticket = p.ticket; tail.expected = p.S;
         tail.C = p.C; tail.groups = p.groups; tail.HW = p.HW; tail.eps = p.eps; tail.stg = p.partial; tail.Sg = p.S;

@@ -19,7 +19,7 @@ python scripts/collect_mfma_busy.py $(find $O/pmc_mfma -name "*counter_collectio
 rm -rf $O/pmc_mfma
 for f in gn_trace_parity pmc_traffic_parity pmc_mfma_busy_parity; do [ -s $O/$f.json ] && cp $O/$f.json profiles/r5_$f.json; done
 RS_PROF_SHAPES=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/shapes.json 2> $O/shapes.err; grep "^\[shapes\]" $O/shapes.err > $O/shapes_parity.txt; wc -l $O/shapes_parity.txt
-timeout 1200 python bench.py --steps 20 --warmup 5 --cpu-seconds ${CPU_SECONDS:-170} > $O/bench_parity_final.json 2> $O/bench_parity_final.err; echo "bench rc=$?"
+(time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5) 2> $O/bench_time.txt > $O/bench_parity_final.json; echo "bench rc=$? $(grep real $O/bench_time.txt)"
 python -c "
 import json; d=json.load(open('$O/bench_parity_final.json')); r=d['roofline']; c=d['cpu_baseline']; t=d.get('torch_rocm_autocast_baseline') or d.get('torch_rocm_autocast_restatement_baseline')
 print(d['value'], d['ms_per_step'], d['ms_per_unet_step'], d['config']['kernel_launches_per_step'], 'frac', r['frac'], 'issue', r['mfma_issue_frac'], 'path', r['frac_whole_path'], 'traffic', r['traffic'], 'busy', (r['mfma_busy'] or {}).get('family_mfma_busy') if isinstance(r['mfma_busy'], dict) else r['mfma_busy'])
@@ -29,6 +29,9 @@ for c in journal faceir inpaint; do
   python -c "
 import json; d=json.load(open('$O/bench_$c.json')); p=d['parity_vs_cpu_oracle'][0]; print('$c', d['value'], d['ms_per_step'], p['image_psnr_db'], p['image_psnr_db_worst_image'], p['vq_code_agreement'], p['checker'], d['value_fp16_unqualified']['value'])"
 done
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_fp16 -o fp16 -- python $R/bench.py --precision fp16 --steps 2 --warmup 1 $B > $O/trace_fp16.log 2>&1)
+db=$(ls $O/trace_fp16/*.db 2>/dev/null | head -1)
+if [ -n "$db" ]; then python scripts/rocpd_summary.py $db --top 24 > $O/kernel_trace_fp16.txt; rm -rf $O/trace_fp16; fi
 RESSHIFT_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 4 --config inpaint --steps 2 --warmup 1 --no-profile-pass > $O/bench_gpus4_inpaint.json 2> $O/bench_gpus4_inpaint.err; echo "gpus4 inpaint rc=$?"
 python -c "
 import json; d=json.load(open('$O/bench_gpus4_inpaint.json')); print('gpus4', d['n_gpus'], d['value'], d['ranks']['backend'], len(d['ranks']['per_rank']), d['ranks']['weight_broadcast_bytes'])"
