@@ -390,7 +390,9 @@ static bool rs_fake_device() {
     static const bool fake = []() {
         if (!getenv("RS_FAKE_DEVICE")) return false;
         int n = 0;
-        return !(hipGetDeviceCount(&n) == hipSuccess && n > 0);
+        const hipError_t e = hipGetDeviceCount(&n);
+        // (only the definite answer "this host has no HIP device" enables the hook - a driver hiccup on a GPU box must not)
+        return e == hipErrorNoDevice || (e == hipSuccess && n == 0);
     }();
     return fake;
 }
