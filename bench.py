@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--exact-leg", action="store_true", help="also run the fp32-policy parity/timing leg (one pass)")
     ap.add_argument("--no-exact-leg", action="store_true", help=argparse.SUPPRESS)   # (round-3 flag, now the default)
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
+    ap.add_argument("--no-unet-step", action="store_true", help="skip the ms_per_unet_step leg (profiling passes: the trace / PMC files must hold whole passes only)")
     ap.add_argument("--no-reference-modules", action="store_true", help="baseline legs on the oracle's restatement even when oracle/_ref is present")
     args = ap.parse_args()
 
@@ -372,7 +373,7 @@ def main():
     # ---- ms/step as SURVEY.md 8(d) defines it: ONE UNet forward + sampler update (models/unet.py:865-895 + gaussian_diffusion.py:332-365) at
     # batch B under the headline policy, through the step-wise API (`p_sample`), hipEvent-bracketed on the launch stream
     unet_step = None
-    if rank == 0:
+    if rank == 0 and not args.no_unet_step:
         ti = steps // 2
         xs = noise[1].contiguous()
         nz = noise[2].contiguous()

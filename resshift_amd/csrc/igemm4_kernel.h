@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void igemm4_kernel(IGemmParams p) {
     // last MFMAs with the weight fragments one channel fragment ahead - behind a barrier the first MFMA waits for one read instead of
     // nine - : 146.4 -> 144.9 ms on the conv layer mix of the microbenchmark, 109.88 vs 109.86 ms of the family in the pass; and s_setprio 1
     // for waves 4 - 7 over the K loop: 110.1 vs 109.9 ms.  profiles/r5_halo_refill_ab.txt.  Neither start-of-stage latency is what a stage
-    // waits for.)
+    // waits for.  Nor is it the LDS-DMA instructions' issue cost: one piece per channel fragment with the two waves of a SIMD half a fragment
+    // apart - waves 0 - 3 in front of fragment i's MFMAs, waves 4 - 7 behind them - is SLOWER, 153.1 vs 146.5 ms / 117.9 vs 113.5 ms in the pass:
+    // every form that takes the two waves of a SIMD out of step costs split storage 4 - 6 %.)
     // FAST (round 5): the refill's per-lane byte offsets - XPW halo pieces and RW weight row groups of this wave - are computed ONCE and
     // kept in registers (10 VGPRs); what changes from stage to stage (chunk, tap) is a scalar and travels in the buffer instruction's
     // SGPR offset.  A stage's refill shrinks from ~100 instructions (pixel decode, bounds tests, 32-bit multiplies, per piece and row

@@ -28,12 +28,18 @@ from resshift_amd import build as _b  # noqa: E402
 KEYS = ("igemm", "swin_mlp", "win_attn", "ae_flash")
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(set)
+dur_ns = defaultdict(dict)   # kernel -> dispatch -> duration of that dispatch in THIS (counter-collecting) pass
 for r in csv.DictReader(open(sys.argv[1])):
     n = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"]).strip()
     if not any(k in n for k in KEYS):
         continue
     acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
-    launches[n].add(r.get("Dispatch_Id", r.get("Correlation_Id", len(launches[n]))))
+    did = r.get("Dispatch_Id", r.get("Correlation_Id", len(launches[n])))
+    launches[n].add(did)
+    try:
+        dur_ns[n][did] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    except (KeyError, ValueError):
+        pass
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 rows = []
 for n, c in acc.items():
@@ -42,7 +48,10 @@ for n, c in acc.items():
         continue
     lds = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
     wav = c.get("SQ_WAVE_CYCLES", 0.0)
+    tns = sum(dur_ns[n].values())
     rows.append({"kernel": n, "launches": len(launches[n]), "gpu_cycles_per_launch": round(gui / max(1, len(launches[n])), 1),
+                 # effective shader clock inside this kernel = GRBM_GUI_ACTIVE per XCD / the dispatches' own durations in the same pass (MI355X_MICROARCH.md, DVFS)
+                 "avg_us_in_this_pass": round(tns / 1e3 / max(1, len(dur_ns[n])), 2) if tns else None, "effective_clock_ghz": round(gui / tns, 3) if tns else None,
                  "share_of_family_cycles": gui,
                  "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / gui, 4),
                  "mfma_instructions_per_launch": round(c.get("SQ_INSTS_MFMA", 0.0) / max(1, len(launches[n])), 1),
@@ -62,4 +71,4 @@ json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}))
 for r in rows[:top]:
     print(f"{r['kernel'][:70]:70s} n={r['launches']:4d} share {r['share_of_family_cycles']:.3f} mfma_busy {r['mfma_busy']:.3f} lds {r['lds_active']:.3f} "
-          f"conflict {r['lds_conflict']} wait_inst {r['wait_inst']} wait_any {r['wait_any']}")
+          f"conflict {r['lds_conflict']} wait_inst {r['wait_inst']} wait_any {r['wait_any']} clock {r['effective_clock_ghz']} GHz")

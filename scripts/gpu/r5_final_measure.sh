@@ -5,7 +5,7 @@
 # per-shape table, the full default bench line (reference modules on the CPU and under autocast on the GPU: oracle/_ref travelled with the
 # snapshot), the other BASELINE configurations, and the 4-rank plumbing run.
 R=$(pwd); O=$R/gpurun_out/r5f; mkdir -p $O; export TMPDIR=/tmp
-B="--no-cpu-baseline --no-profile-pass --no-secondary"
+B="--no-cpu-baseline --no-profile-pass --no-secondary --no-unet-step"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_parity -o parity -- python $R/bench.py --steps 2 --warmup 1 $B > $O/trace_parity.log 2>&1)
 db=$(ls $O/trace_parity/*.db 2>/dev/null | head -1); echo "db=$db"
 if [ -n "$db" ]; then python scripts/rocpd_summary.py $db --top 36 > $O/kernel_trace_parity.txt; python scripts/collect_gn_trace.py $db 3 $O/gn_trace_parity.json; rm -rf $O/trace_parity; fi
@@ -18,7 +18,7 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 python scripts/collect_mfma_busy.py $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) $O/pmc_mfma_busy_parity.json 14 > $O/pmc_mfma_busy_parity.txt 2>&1; tail -16 $O/pmc_mfma_busy_parity.txt | cut -c1-220
 rm -rf $O/pmc_mfma
 for f in gn_trace_parity pmc_traffic_parity pmc_mfma_busy_parity; do [ -s $O/$f.json ] && cp $O/$f.json profiles/r5_$f.json; done
-RS_PROF_SHAPES=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/shapes.json 2> $O/shapes.err; grep "^\[shapes\]" $O/shapes.err > $O/shapes_parity.txt; wc -l $O/shapes_parity.txt
+RS_PROF_SHAPES=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-unet-step > $O/shapes.json 2> $O/shapes.err; grep "^\[shapes\]" $O/shapes.err > $O/shapes_parity.txt; wc -l $O/shapes_parity.txt
 (time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5) 2> $O/bench_time.txt > $O/bench_parity_final.json; echo "bench rc=$? $(grep real $O/bench_time.txt)"
 python -c "
 import json; d=json.load(open('$O/bench_parity_final.json')); r=d['roofline']; c=d['cpu_baseline']; t=d.get('torch_rocm_autocast_baseline') or d.get('torch_rocm_autocast_restatement_baseline')
