@@ -72,7 +72,19 @@ def init_distributed() -> Tuple[int, int]:
         kw = {}
         if backend == "nccl":   # bind the communicator to this rank's device up front (no lazy device guess at the first collective)
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
+        # (gloo / RCCL print connection banners from C++ straight to fd 1; a caller's stdout may be a protocol - bench.py's is ONE JSON line -
+        # so fd 1 points at stderr while the communicator comes up)
+        import sys
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return world, rank
 
 
