@@ -2,7 +2,7 @@
 # Round 5: A/B of the halo kernel's K-loop refill (igemm4_kernel.h; libs built with RS_BUILD_DEFS="RS_IG4_FAST=f RS_IG4_SCHED=s" RS_BUILD_OUT=ablib/f<f>s<s>.so):
 #   FAST  1 = precomputed per-lane offsets + scalar chunk / tap offset, 0 = round 4's address arithmetic in every stage
 #   SCHED 0 = refill right behind the barrier (round 4), 1 = waves 0-3 in front of their MFMAs / waves 4-7 behind the first channel fragments,
-#         2 = every wave behind its first channel fragment.     main = FAST 1, SCHED 2.
+#         2 = every wave behind its first channel fragment.     main = FAST 1, SCHED 2 (split) / 1 (fp16): the shipped defaults.
 #   gpurun --timeout 900 -- bash scripts/gpu/r5_sched_ab.sh
 R=$(pwd); O=$R/gpurun_out/r5s2; mkdir -p $O; export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "halo or conv_igemm or conv_concat" > $O/pytest_ops.log 2>&1; echo "op tests rc=$?"; tail -2 $O/pytest_ops.log
