@@ -3,7 +3,7 @@ SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE - eight SQ slots + on
 slots") into profiles/<name>.json: matrix-pipe and LDS utilisation per kernel instantiation of the MFMA families (north_star: "choices
 evidenced by rocprof HBM GB/s and MFMA-busy").
 
-    python scripts/collect_mfma_busy.py <counter_collection.csv> <out.json> [top N, default 12]
+    python scripts/collect_mfma_busy.py <counter_collection.csv> <out.json> [top N, default 12] [policy label, default "parity"]
 
 Normalisation (as profiles/r2_igemm4_ablation.txt §5): SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1 024 SIMDs, SQ_LDS_IDX_ACTIVE over
 its 256 CUs, GRBM_GUI_ACTIVE over its 8 XCDs, so
@@ -63,7 +63,8 @@ for r in rows:
     r["share_of_family_cycles"] = round(r["share_of_family_cycles"] / tot, 4)
 rows.sort(key=lambda r: -r["share_of_family_cycles"])
 fam_busy = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for c in acc.values()) / 1024.0 / tot
-out = {"what": "rocprofv3 --pmc of `bench.py --steps 1 --warmup 1` (parity policy, batch 32): matrix-pipe / LDS utilisation per kernel instantiation of the MFMA "
+label = sys.argv[4] if len(sys.argv) > 4 else "parity"
+out = {"what": f"rocprofv3 --pmc of `bench.py --steps 1 --warmup 1` ({label} policy, batch 32): matrix-pipe / LDS utilisation per kernel instantiation of the MFMA "
                "families, heaviest first; see scripts/collect_mfma_busy.py for the normalisation",
        "family_mfma_busy": round(fam_busy, 4), "instantiations": len(rows), "per_kernel": rows[:top],
        "kernel_source_digest": _b._digest()[:16]}

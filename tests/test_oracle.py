@@ -227,3 +227,38 @@ def test_respaced_schedule_live_against_reference():
         r = np.asarray(getattr(ref, name), dtype=np.float64)
         assert np.array_equal(r, np.asarray(getattr(s, name), dtype=np.float64)), name
         assert np.array_equal(r, np.asarray(getattr(mine, name), dtype=np.float64)), name
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference modules (tree or verified oracle/_ref copy) not present")
+def test_reference_baseline_wrapper_runs_the_reference_loop_and_agrees_with_the_oracle(capsys):
+    """bench.py's baseline legs (oracle/ref_baseline.py: `cpu_baseline.kind = "reference"`, `torch_rocm_autocast_baseline`) drive the UNMODIFIED
+    modules' p_sample_loop_progressive + decode_first_stage with injected noise.  On the tiny case: same image / latent / VQ indices as the
+    oracle's restatement (which is pinned to the reference elsewhere in this file), and nothing on stdout - bench.py's stdout is ONE JSON line
+    and the reference prints notices while it is imported and constructed."""
+    from oracle import ref_baseline
+
+    up, ap, dp, _ = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    y, noises, _ = H.synth.synthetic_inputs(H.SEED_X, 2, 16, 16, ap["embed_dim"], 16, 16, dp["steps"])
+    capsys.readouterr()
+    ref = ref_baseline.Reference(up, ap, dp, usd, asd)
+    img, z, idx = ref.sample(y, noises)
+    assert capsys.readouterr().out == ""
+    o_img, aux = oc.sample_loop(usd, up, asd, ap, dp, y, noises, return_aux=True)
+    assert torch.equal(idx, aux["indices"].reshape(2, -1))
+    assert (img - o_img).abs().max().item() < 1e-4 and (z - aux["z_final"]).abs().max().item() < 1e-4
+
+
+def test_winograd_study_transform_is_the_direct_convolution():
+    """oracle/study_winograd.py decides a kernel design on the CPU; its F(2x2, 3x3) emulation must BE a 3x3 / pad-1 convolution:
+    fp32 operands reproduce F.conv2d to fp32 rounding, pair operands to the pair's 2^-22."""
+    from oracle import study_winograd as sw
+
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(2, 32, 8, 12, generator=g), torch.randn(48, 32, 3, 3, generator=g) / 17.0, torch.randn(48, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    sd = {"t.weight": w, "t.bias": b}
+    for split, tol in ((False, 2e-6), (True, 4e-6)):
+        sw._U.clear()
+        got = sw.wino(sd, "t", x, split)
+        assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < tol
