@@ -34,7 +34,7 @@ class Reference:
             self.ae = V(**aep).eval()
             self.ae.load_state_dict(asd, strict=True)
             self.diffusion = create(**dp)
-        self.source = ("verified copy of the reference's modules (oracle/_ref, sha256 manifest checked)" if ref_import.is_copy()
+        self.source = ("verified copy of the reference's modules (oracle/_ref/reference_modules.zip, sha256 manifest checked)" if ref_import.is_copy()
                        else f"reference tree at {ref_import.REF}")
 
     def to(self, dev):

@@ -1,9 +1,9 @@
 """ORACLE support — imports the UNMODIFIED reference modules so that oracle/make_golden.py and tests/test_oracle.py can pin
 the restatement in resshift_oracle.py against the real thing, and so that bench.py's baseline legs can time the reference itself.
 
-Where the modules come from, in this order: $RESSHIFT_REFERENCE, /root/reference (the build container), oracle/_ref/ (the byte-identical,
-git-ignored copy oracle/make_ref_copy.py makes of the hot-path modules; it is what exists on the GPU box - its sha256 manifest is
-verified before anything is imported from it).  The reference needs `timm` for three init helpers (models/swin_transformer.py:13); a stub
+Where the modules come from, in this order: $RESSHIFT_REFERENCE, /root/reference (the build container), oracle/_ref/reference_modules.zip
+(the git-ignored archive oracle/make_ref_copy.py packs the hot-path modules into, byte for byte; it is what exists on the GPU box - the
+archive's and every member's sha256 are verified against the manifest before anything is imported from it; Python imports from the zip).  The reference needs `timm` for three init helpers (models/swin_transformer.py:13); a stub
 package providing them is injected.  Test / measurement infrastructure: nothing under resshift_amd/ imports this module.
 """
 from __future__ import annotations
@@ -13,34 +13,47 @@ import sys
 import types
 
 COPY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+ARCHIVE = "reference_modules.zip"
 
 
 def _copy_ok() -> bool:
-    """oracle/_ref exists and every file matches the manifest make_ref_copy.py wrote (an edited copy is not "the reference")"""
+    """oracle/_ref/reference_modules.zip exists and it and every member match the manifest make_ref_copy.py wrote (an edited copy is not
+    "the reference")"""
     import hashlib
     import json
+    import zipfile
 
-    mpath = os.path.join(COPY, "MANIFEST.json")
-    if not os.path.exists(mpath):
+    mpath, zpath = os.path.join(COPY, "MANIFEST.json"), os.path.join(COPY, ARCHIVE)
+    if not (os.path.exists(mpath) and os.path.exists(zpath)):
         return False
     try:
         with open(mpath) as fh:
-            man = json.load(fh)["sha256"]
-        for rel, dig in man.items():
-            with open(os.path.join(COPY, rel), "rb") as fh:
-                if hashlib.sha256(fh.read()).hexdigest() != dig:
+            man = json.load(fh)
+        with open(zpath, "rb") as fh:
+            if hashlib.sha256(fh.read()).hexdigest() != man["archive_sha256"]:
+                return False
+        with zipfile.ZipFile(zpath) as z:
+            names = {n for n in z.namelist() if not n.endswith("/")}
+            if names != set(man["sha256"]):
+                return False
+            for rel, dig in man["sha256"].items():
+                if hashlib.sha256(z.read(rel)).hexdigest() != dig:
                     return False
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, zipfile.BadZipFile):
         return False
-    return "models/unet.py" in man
+    return "models/unet.py" in man["sha256"]
+
+
+def _copy_path() -> str:
+    return os.path.join(COPY, ARCHIVE)
 
 
 def where() -> "str | None":
     """directory the reference modules would be imported from, or None"""
     for cand in (os.environ.get("RESSHIFT_REFERENCE"), "/root/reference"):
-        if cand and os.path.isdir(os.path.join(cand, "models")):
+        if cand and (os.path.isdir(os.path.join(cand, "models")) or (cand.endswith(".zip") and os.path.isfile(cand))):
             return cand
-    return COPY if _copy_ok() else None
+    return _copy_path() if _copy_ok() else None
 
 
 REF = where() or "/root/reference"
@@ -51,7 +64,7 @@ def available() -> bool:
 
 
 def is_copy() -> bool:
-    return where() == COPY
+    return where() == _copy_path()
 
 
 def load(prefer: "str | None" = None):

@@ -326,22 +326,32 @@ def test_rccl_branch_binds_the_device_names_it_in_barriers_and_broadcasts_device
 
 
 def test_reference_copy_is_verified_before_it_is_used(tmp_path, monkeypatch):
-    """oracle/_ref (the git-ignored copy of the reference's hot-path modules that bench.py's baseline legs import on the GPU box) counts as
-    "the reference" only while every file matches the sha256 manifest oracle/make_ref_copy.py wrote."""
+    """oracle/_ref/reference_modules.zip (the git-ignored archive of the reference's hot-path modules that bench.py's baseline legs import on the GPU
+    box) counts as "the reference" only while the archive and every member match the sha256 manifest oracle/make_ref_copy.py wrote."""
     import hashlib
     import json
+    import zipfile
 
     from oracle import ref_import
 
     root = tmp_path / "_ref"
-    (root / "models").mkdir(parents=True)
-    (root / "models" / "unet.py").write_text("x = 1\n")
-    man = {"models/unet.py": hashlib.sha256(b"x = 1\n").hexdigest()}
-    (root / "MANIFEST.json").write_text(json.dumps({"sha256": man}))
+    root.mkdir()
+
+    def pack(body: bytes):
+        with zipfile.ZipFile(root / "reference_modules.zip", "w") as z:
+            z.writestr("models/", "")
+            z.writestr("models/unet.py", body)
+        return hashlib.sha256((root / "reference_modules.zip").read_bytes()).hexdigest()
+
+    digest = pack(b"x = 1\n")
+    (root / "MANIFEST.json").write_text(json.dumps({"archive_sha256": digest, "sha256": {"models/unet.py": hashlib.sha256(b"x = 1\n").hexdigest()}}))
     monkeypatch.setattr(ref_import, "COPY", str(root))
     assert ref_import._copy_ok()
-    (root / "models" / "unet.py").write_text("x = 2\n")
+    pack(b"x = 2\n")                                    # an edited member (and with it another archive)
     assert not ref_import._copy_ok()
+    digest = pack(b"x = 1\n")
+    (root / "MANIFEST.json").write_text(json.dumps({"archive_sha256": digest, "sha256": {"models/unet.py": "0" * 64}}))
+    assert not ref_import._copy_ok()                    # the archive matches, the member does not
     (root / "MANIFEST.json").unlink()
     assert not ref_import._copy_ok()
 
