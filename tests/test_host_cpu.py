@@ -507,3 +507,35 @@ def test_weight_forms_and_sampler_policies():
     assert sharding.weight_forms(set(BaseSampler.POLICIES["parity"])) == dict(enable_f16=True, enable_f32=False, enable_split=True)
     with pytest.raises(KeyError):
         sharding.weight_forms(["fp8"])
+
+
+def test_subpixel_form_of_upsample_conv_is_exact_algebra():
+    """The algebra behind engine.hip add_upfold, restated in torch on the CPU: nearest x2 + conv3x3 (models/unet.py:53-81,
+    ldm/modules/diffusionmodules/model.py:50-65) == four 2x2 convs over the LOW-resolution grid (pad_t = 1 - py, pad_l = 1 - px, i.e. rows
+    {y - 1 + py, y + py}) whose weights are the sums of the taps that land on the same source pixel, outputs interleaved by parity.  In float64
+    the two forms agree to rounding - including the borders, where zero padding of the upsampled image is zero padding of the source.  (The C++
+    packer and the kernels' row scatter are pinned on the GPU: test_upsample_subpixel_form_matches_the_folded_address_conv.)"""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(4, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+
+    def taps(par, d):   # taps of one axis that land on source offset d (0 / 1, relative to y - 1 + par) for output parity par
+        return [k for k in range(3) if ((par + k - 1) >> 1) - (par - 1) == d]
+
+    out = torch.empty_like(ref)
+    for py in (0, 1):
+        for px in (0, 1):
+            w2 = torch.zeros(4, 5, 2, 2, dtype=torch.float64)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    for ky in taps(py, dy):
+                        for kx in taps(px, dx):
+                            w2[:, :, dy, dx] += w[:, :, ky, kx]
+            xp = F.pad(x, (1 - px, px, 1 - py, py))          # (left, right, top, bottom): the 2x2 window starts at (y - 1 + py, x - 1 + px)
+            out[:, :, py::2, px::2] = F.conv2d(xp, w2, b)
+    assert [len(taps(0, 0)), len(taps(0, 1)), len(taps(1, 0)), len(taps(1, 1))] == [1, 2, 2, 1]
+    assert (out - ref).abs().max().item() < 1e-12
