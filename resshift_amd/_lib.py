@@ -102,6 +102,7 @@ SIGNATURES = {
     "rs_op_conv2d_bench": (_I, [_P, _P, _P, _P, _P] + [_I] * 16 + [C.POINTER(C.c_float), _P]),
     "rs_op_conv3x3_halo_stats_px": (_I, [_I, _I, _I, _I, _I, _I]),
     "rs_op_conv3x3_halo": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "rs_op_conv3x3_wino": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, C.POINTER(C.c_float), _P]),
     "rs_op_gemm_nt": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "rs_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "rs_op_window_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build" + ("_" + hashlib.sha256(os.environ["RS_BUILD_DEFS"].encode()).hexdigest()[:8] if os.environ.get("RS_BUILD_DEFS") else ""))
 LIB = os.environ.get("RS_BUILD_OUT") or os.path.join(HERE, "libresshift_hip.so")   # (RS_BUILD_OUT / RS_BUILD_DEFS: A/B builds of one source tree)
-SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm4.hip", "igemm4s.hip", "igemm_split.hip", "swin_mlp.hip", "direct_conv.hip", "norm_attn.hip", "win_attn_split.hip", "ae_attn.hip", "ae_attn_split.hip", "elementwise.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "igemm4.hip", "igemm4s.hip", "wino.hip", "igemm_split.hip", "swin_mlp.hip", "direct_conv.hip", "norm_attn.hip", "win_attn_split.hip", "ae_attn.hip", "ae_attn_split.hip", "elementwise.hip", "engine.hip"]
 HEADERS = ["common.h", "igemm_common.h", "igemm4_kernel.h", "gn_tail.h", os.path.join("..", "..", "include", "resshift_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -261,6 +261,9 @@ struct IGemmParams {
     // igemm3 / igemm_split), no residual, no split-K; output statistics from igemm_split only (the four launches fill ONE slab array -
     // an image's slabs are class 0's tiles, then class 1's, ... - and share the GroupNorm tail's ticket).  osc == 0 / 1: none.
     int osc, ooy, oox;
+    // Winograd F(2x2,3x3) form of this layer's weights (wino.hip: rs_wino_pack order; split storage only), or null: with it a 3x3 / stride-1
+    // conv on a plane that tiles by 16 x 16 runs on wino_kernel instead of the halo kernel (rs_wino_plan)
+    const void* ww;
 };
 
 #if defined(__HIPCC__)

@@ -37,6 +37,10 @@ int rs_igemm_splitk_plan(int M, int Cout, int Ktot, int in_dt);
 int rs_igemm4_pick(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC);
 int rs_igemm4_plan(const IGemmParams* p, int in_dt, int out_dt, int nz, int* TW, int* BC, int* SEG, int* SK);
 int rs_igemm4_stats_px(const IGemmParams* p, int in_dt);
+int rs_wino_plan(const IGemmParams* p, int in_dt, int out_dt, int nz);
+int rs_wino_launch(const IGemmParams* p, hipStream_t st);
+size_t rs_wino_weight_bytes(int Cin, int Cout);
+float rs_wino_pack(const float* w_ref, int Cin, int Cout, void* dst);
 int rs_igemm_split_stats_px(const IGemmParams* p, int splitk);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_head_conv_launch(const void* x, int in_dt, const float* coef_dev, const float* w_dev, const float* bias_dev, float* y, int B, int H, int W, int C,
@@ -2215,6 +2219,46 @@ int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const f
     }
     (void)hipStreamSynchronize(st);
     if (part) (void)hipFree(part);
+    if (wdev) (void)hipFree(wdev);
+    if (bias) (void)hipFree(bias);
+    return rc;
+}
+
+// The same layer on the Winograd F(2x2,3x3) kernel (wino.hip; split storage only): weights transformed and packed on the host, one checked
+// launch; with reps > 0 the launch is then repeated `reps` times between two hipEvents and *ms_out receives the average milliseconds.
+// `ystats_dev`: [B][H*W / 256][Cout][2] (one slab per 16 x 16 pixel tile).  Fails when the shape is not eligible.
+int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res, void* y,
+                       int B, int H, int W, int Cin, int Cout, float* ystats_dev, int reps, float* ms_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin < 32 || (Cin % 32) || Cout < 32 || (Cout % 32)) return fail("wino kernel: channels in multiples of 32");
+    std::vector<char> packed(rs_wino_weight_bytes(Cin, Cout));
+    const float mx = rs_wino_pack(w_ref_host, Cin, Cout, packed.data());
+    if (!(mx < 30.0f)) return fail("wino kernel: |U| >= 30");
+    void* wdev = dev_copy(packed.data(), packed.size());
+    float* bias = bias_host ? (float*)dev_copy(bias_host, Cout * 4) : nullptr;
+    IGemmParams p{};
+    p.x0 = x; p.ww = wdev; p.bias = bias; p.res = res; p.y = y; p.C0 = Cin; p.ld0 = Cin; p.B = B; p.Hs = H; p.Ws = W; p.up = 1; p.Ho = H; p.Wo = W;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = 9 * Cin;
+    p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in; p.ystats = ystats_dev; p.ystats_ld = Cout;
+    int rc = 0;
+    if (!rs_wino_plan(&p, RS_F16S, RS_F16S, 1)) rc = fail("shape is not eligible for the wino kernel");
+    else {
+        rc = rs_wino_launch(&p, st);
+        if (rc) fail("wino launch failed");
+        if (!rc && reps > 0) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < reps; ++i) rc |= rs_wino_launch(&p, st);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms_out) *ms_out = ms / (float)reps;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+    }
+    (void)hipStreamSynchronize(st);
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);
     return rc;

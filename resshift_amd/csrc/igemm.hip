@@ -368,6 +368,8 @@ extern "C" int rs_igemm3_pick(int M, int Cout, int Ktot, int in_dt, int nz, int 
 extern "C" int rs_igemm3_launch(const IGemmParams* pp, int out_dt, int BC, hipStream_t st);
 extern "C" int rs_igemm4_pick(const IGemmParams* pp, int in_dt, int out_dt, int nz, int* TW, int* BC);
 extern "C" int rs_igemm4_launch(const IGemmParams* pp, int in_dt, int TW, int BC, hipStream_t st);
+extern "C" int rs_wino_plan(const IGemmParams* pp, int in_dt, int out_dt, int nz);
+extern "C" int rs_wino_launch(const IGemmParams* pp, hipStream_t st);
 extern "C" void rs_igemm_split_pick(int M, int Cout, int nz, int* BP, int* BC);
 extern "C" int rs_igemm_split_launch(const IGemmParams* pp, int out_dt, int nz, hipStream_t st);
 
@@ -426,6 +428,8 @@ extern "C" int rs_igemm_launch(const IGemmParams* pp, int in_dt, int out_dt, int
     // statistics and the split-K slabs are all indexed by the GEMM row
     // (output statistics: the split-storage kernel only - its four launches fill one slab array and share the GroupNorm tail's ticket)
     if (p.osc != 0 && p.osc != 1 && (p.osc != 2 || p.res || (p.ystats && in_dt != RS_F16S) || p.splitk > 1 || nz != 1 || p.up != 1 || p.stride != 1 || p.C1 != 0)) return -2;
+    // Winograd F(2x2,3x3) kernel (split storage, big planes; carries the halo kernel's input transform / statistics / tail): wino.hip
+    if (rs_wino_plan(&p, in_dt, out_dt, nz)) return rs_wino_launch(&p, st);
     {   // halo-tile kernel (3x3 stride-1 convs, optional fused GroupNorm affine + SiLU on the input): igemm4.hip
         int tw4 = 0, bc4 = 0;
         if (rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw4, &bc4)) return rs_igemm4_launch(&p, in_dt, tw4, bc4, st);

@@ -750,6 +750,46 @@ def test_conv3x3_halo_split_storage(gpu, case):
     assert ((st.cpu().double().sum(1) - _stats_ref(ref)).abs() / (_stats_ref(ref).abs() + 1.0)).max().item() < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    (4, 64, 64, 160, 160, True, True),      # the UNet's 64 x 64 level: 5 chunks, channel blocks 64 + 64 + 32
+    (8, 32, 32, 320, 320, True, True),      # 32 x 32 level: 5 blocks of 64
+    (2, 32, 48, 640, 320, True, False),     # concat input (the coefficient table's limit), non-square plane
+    (1, 128, 128, 128, 128, False, True),   # AE: plain conv (no input transform), residual
+    (3, 16, 16, 32, 32, True, True),        # one chunk, one narrow block, one tile per image (all four borders in every tile)
+    (2, 16, 32, 96, 64, False, False),
+])
+def test_conv3x3_wino_split_storage(gpu, case):
+    """wino.hip: Winograd F(2x2,3x3) on (hi, lo) pairs - GroupNorm affine + SiLU applied to the joined value in LDS, V = B^T d B per
+    position straight from the fp32 halo, three MFMAs per product, output transform through LDS, residual, statistics; float64 reference
+    of the reference's nn.Conv2d(3x3, padding 1) (models/unet.py:147,173).  The transform's own rounding is about one bit on top of the
+    direct split kernel's 3e-6."""
+    from resshift_amd import ops
+
+    B, H, W, Cin, Cout, use_coef, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xr = x.double()
+    coef_d = None
+    if use_coef:
+        a = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+        d = torch.randn(B, Cin, generator=g) * 0.5
+        coef_d = torch.stack([a, d], 1).contiguous().to(gpu)
+        xr = F.silu(xr * a.double()[:, :, None, None] + d.double()[:, :, None, None])
+    ref = F.conv2d(xr, w.double(), bias.double(), padding=1)
+    res_d = None
+    if use_res:
+        r = torch.randn(ref.shape, generator=g)
+        res_d = _split(r, gpu)
+        ref = ref + r.double()
+    y, st = ops.conv3x3_wino(_split(x, gpu), w, bias, coef=coef_d, act_in=2 if use_coef else 0, res=res_d, want_stats=True)
+    torch.cuda.synchronize()
+    _close(_unsplit(y).permute(0, 3, 1, 2), ref, 6e-6, f"wino conv {case}")
+    assert ((st.cpu().double().sum(1) - _stats_ref(ref)).abs() / (_stats_ref(ref).abs() + 1.0)).max().item() < 1e-3
+
+
 # small planes of the 16 x 16 / 8 x 8 UNet levels on the halo kernel (igemm4_kernel.h, SEG > 0): four 8 x 8 images or one 16 x 16 image per
 # tile, split-K over the (chunk, tap) stage sequence with slices that start / end in the middle of a chunk, reduce kernel with the
 # GroupNorm statistics of the stored output.  (B, H, W, Cin, Cout, coef, res)
