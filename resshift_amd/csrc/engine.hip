@@ -2241,10 +2241,30 @@ int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const f
     p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.Cout = Cout; p.ldy = Cout; p.ldres = Cout; p.M = B * H * W; p.Ktot = 9 * Cin;
     p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in; p.ystats = ystats_dev; p.ystats_ld = Cout;
     int rc = 0;
+    float* stamps = nullptr;   // RS_WINO_STAMPS=1 with a -DRS_WINO_PHASES build: per-workgroup phase cycles of wave 0 (see wino.hip), averaged to stderr
+    const int ntile = B * (H / 16) * (W / 16) * ((Cout + 63) / 64);
+    if (const char* ab = getenv("RS_WINO_ABL")) p.dbg = atoi(ab);   // (-DRS_WINO_PHASES builds: timing ablations, wino.hip)
+    if (getenv("RS_WINO_STAMPS")) { (void)hipMalloc((void**)&stamps, (size_t)ntile * 8 * sizeof(float)); (void)hipMemset(stamps, 0, (size_t)ntile * 8 * sizeof(float)); p.partial = stamps; }
     if (!rs_wino_plan(&p, RS_F16S, RS_F16S, 1)) rc = fail("shape is not eligible for the wino kernel");
     else {
         rc = rs_wino_launch(&p, st);
         if (rc) fail("wino launch failed");
+        if (stamps) {
+            (void)hipStreamSynchronize(st);
+            std::vector<float> hs((size_t)ntile * 8);
+            (void)hipMemcpy(hs.data(), stamps, hs.size() * sizeof(float), hipMemcpyDeviceToHost);
+            const int nby = (Cout + 63) / 64;
+            double wide[8] = {}, narrow[8] = {}; int nw = 0, nn = 0;
+            for (int t = 0; t < ntile; ++t) {   // (tile ids are XCD-remapped inside the kernel; the stamps are indexed by blockIdx - classify by the total instead)
+                for (int i = 0; i < 8; ++i) wide[i] += hs[(size_t)t * 8 + i];
+                ++nw;
+            }
+            (void)narrow; (void)nn; (void)nby;
+            static const char* nm[8] = {"prologue", "wait+barrier", "halo issue", "B operand", "MFMA steps", "conversion", "epilogue", "total"};
+            fprintf(stderr, "[wino phases] %dx%dx%d %d->%d, mean cycles of wave 0 over %d workgroups:", B, H, W, Cin, Cout, nw);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", nm[i], wide[i] / std::max(1, nw));
+            fprintf(stderr, "\n");
+        }
         if (!rc && reps > 0) {
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -2259,6 +2279,7 @@ int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const f
         }
     }
     (void)hipStreamSynchronize(st);
+    if (stamps) (void)hipFree(stamps);
     if (wdev) (void)hipFree(wdev);
     if (bias) (void)hipFree(bias);
     return rc;

@@ -48,15 +48,14 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 constexpr int W_PITCH = 20;                 // halo row pitch in LDS rows (18 columns deinterleaved: evens at 0..8, odds at 10..18; 9 and 19 stay zero)
 constexpr int W_HROWS = 18 * W_PITCH;       // 360 LDS rows of 128 B = 45 LDS-DMA pieces of 1 KB
-constexpr int W_HBUF = W_HROWS * 128;       // 46 080 B per halo buffer
-constexpr int W_NUNIT = (W_HROWS + 15) / 16;   // 16-row units (2 KB: two DMA pieces = one in-place conversion instruction of a wave): 23
-constexpr int W_UPW = (W_NUNIT + 7) / 8;    // units per wave (wave w owns units w, w + 8, w + 16): 3
+constexpr int W_UPW = 3;                    // 16-row units (2 KB: two DMA pieces = one in-place conversion instruction) per wave: wave w owns units w, w + 8, w + 16
+constexpr int W_NUNIT = 8 * W_UPW;          // 24 units = 384 rows: rows 360 .. 383 exist only so that all waves run the same code (zeros, never read)
+constexpr int W_HBUF = W_NUNIT * 2048;      // 49 152 B per halo buffer
 constexpr int W_NBUF = 3;                   // halo buffers: chunk c computes, chunk c + 1 is converted, chunk c + 2 lands
 constexpr int W_COEF = W_NBUF * W_HBUF;     // GroupNorm coefficients [2][Cin] fp32
 constexpr int W_LDS = 160 * 1024;
 constexpr int W_MAXCIN = 640;               // coefficient table: 5 120 B
-constexpr int W_DUMMY = W_COEF + W_MAXCIN * 8;   // 1 KB nobody reads: target of the LDS-DMA pieces that do not exist (every wave issues six per chunk)
-static_assert(W_DUMMY + 1024 <= W_LDS, "LDS");
+static_assert(W_COEF + W_MAXCIN * 8 <= W_LDS, "LDS");
 constexpr int W_TS = 272;                   // epilogue exchange: bytes per (position, tile) row = 64 channels fp32 + 16 (bank spread)
 constexpr unsigned W_INV = 0xF0000000u;
 
@@ -66,6 +65,18 @@ __host__ __device__ constexpr int w_second(int i) { return i == 3 ? 3 : 2; }
 __host__ __device__ constexpr float w_tau(int i) { return i == 1 ? 1.f : -1.f; }
 __host__ __device__ constexpr float w_sigma(int i) { return i == 2 ? -1.f : 1.f; }
 
+// -DRS_WINO_PHASES: wave 0 of every workgroup accumulates the cycles it spends per phase (s_memtime) into IGemmParams::partial
+// [workgroup][8]: 0 prologue, 1 wait + barrier, 2 halo issue, 3 B operand, 4 MFMA steps, 5 conversion, 6 epilogue, 7 total
+// ... and IGemmParams::dbg switches work off (timing ablations, results wrong): 1 no MFMAs, 2 no B operand formation, 4 no conversion,
+// 8 no weight loads behind the prologue, 16 no epilogue
+#ifdef RS_WINO_PHASES
+#define WSTAMP(i) do { const long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tprev; tprev = t_; } while (0)
+#define WABL(bit) (p.dbg & (bit))
+#else
+#define WSTAMP(i) do {} while (0)
+#define WABL(bit) false
+#endif
+
 template <int CF>
 __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int nb, int txb, int tyb, int b) {
     static_assert(CF == 4 || CF == 2, "channel block of 64 or 32");
@@ -73,6 +84,11 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int txb_n = p.Wo / 16, tyb_n = p.Ho / 16;
     const int n0 = nb * 64, y0 = tyb * 16, x0 = txb * 16;
+#ifdef RS_WINO_PHASES
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
+    const long long tstart = tprev;
+#endif
     const int Cin = p.C0, ld0 = p.ld0, Hs = p.Hs, Ws = p.Ws;
     const int nch = Cin / 32;
     const float* const xcoef = p.xcoef;
@@ -105,7 +121,7 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
             const int unit = wave + 8 * k, row = 16 * unit + 8 * h + (lane >> 3), slot = lane & 7;
             const int g = (slot >> 1) ^ ((row >> 1) & 3);
             unsigned pix;
-            const bool ok = unit < W_NUNIT && row_src(row, pix);
+            const bool ok = row_src(row, pix);
             xv[k][h] = ok ? pix * (unsigned)ld0 * 4u + (unsigned)(slot & 1) * (unsigned)ld0 * 2u + (unsigned)g * 16u : W_INV;
         }
     auto issue_halo = [&](int c, int buf) __attribute__((always_inline)) {   // chunk c -> halo buffer `buf` = c % 3 (c >= nch: zeros; keeps the counted wait static)
@@ -115,10 +131,7 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
         for (int k = 0; k < W_UPW; ++k)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                // (45 pieces: waves 0-5 own six, wave 6 five, wave 7 four - the missing ones go, as zeros, to the dummy slot, so that every
-                // wave has the same number of loads in flight and the counted waits below are the same straight-line code for all of them)
-                const bool real = 2 * (wave + 8 * k) + h < W_HROWS / 8;
-                wdma16s(rx, real ? hb + (wave + 8 * k) * 2048 + h * 1024 : smem + W_DUMMY, (live && real) ? xv[k][h] : W_INV, (unsigned)c * 64u);
+                wdma16s(rx, hb + (wave + 8 * k) * 2048 + h * 1024, live ? xv[k][h] : W_INV, (unsigned)c * 64u);
             }
     };
     // in-place conversion of this wave's units of chunk c: (hi, lo) pair -> GroupNorm affine (+FiLM) -> SiLU -> fp32.  Lane = (row, g'): the
@@ -128,7 +141,7 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
     for (int k = 0; k < W_UPW; ++k) {
         unsigned pix;
         const int unit = wave + 8 * k;
-        if (unit < W_NUNIT && row_src(16 * unit + (lane >> 2), pix)) in_mask |= 1u << k;
+        if (row_src(16 * unit + (lane >> 2), pix)) in_mask |= 1u << k;
     }
     const int cv_g = (lane & 3) ^ (((lane >> 2) >> 1) & 3);   // channel group of this lane's cells (the same in all its units: 16 unit rows leave the key alone)
     const float* const coefs = (const float*)(smem + W_COEF);
@@ -142,15 +155,16 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
         char* hb = smem + buf * W_HBUF + lane * 32;
 #pragma unroll
         for (int k = 0; k < W_UPW; ++k) {
-            if (wave + 8 * k >= W_NUNIT) continue;
-            if (!((in_mask >> k) & 1)) continue;
+            // (no branch on the cell's position: a row outside the image holds zeros and gets zeros back)
+            const bool in = (in_mask >> k) & 1;
             char* cell = hb + (wave + 8 * k) * 2048;
             const f16x8 vh = *(const f16x8*)cell, vl = *(const f16x8*)(cell + 16);
             f32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float t = fmaf(rs_join(vh[e], vl[e]), e < 4 ? ca0[e & 3] : ca1[e & 3], e < 4 ? cd0[e & 3] : cd1[e & 3]);
-                const float u = ACT == RS_ACT_SILU ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : t;
+                float u = ACT == RS_ACT_SILU ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : t;
+                u = in ? u : 0.f;
                 if (e < 4) o0[e & 3] = u; else o1[e & 3] = u;
             }
             *(f32x4*)cell = o0; *(f32x4*)(cell + 16) = o1;
@@ -171,7 +185,7 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
     const int wpos_step = nch * CF * 2048;
     const int wvl = lane * 16;
     auto load_w = [&](int c, int pp, int cf, f16x8& h, f16x8& l) __attribute__((always_inline)) {
-        const int cc = min(c, nch - 1);   // (the prefetch behind the last step re-reads the last chunk)
+        const int cc = min(c, nch - 1);   // (the reload behind the last phase re-reads the last chunk)
         const char* q = wbase + pp * wpos_step + (cc * CF + cf) * 2048 + wvl;
         h = *(const f16x8*)q; l = *(const f16x8*)(q + 1024);
     };
@@ -201,75 +215,76 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
 #pragma unroll
             for (int i = 0; i < CF; ++i) acc[pp][tf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: coefficients -> LDS, chunks 0 and 1 on their way, chunk 0 converted
+    // ---- prologue: coefficients -> LDS, chunks 0 and 1 on their way, chunk 0 converted, the first position's weights
     if (xcoef) {
         const float* src = xcoef + (long long)b * 2 * Cin;
         for (int i = tid; i < 2 * Cin; i += 512) ((float*)(smem + W_COEF))[i] = src[i];
     }
     issue_halo(0, 0);
     issue_halo(1, 1);
-    f16x8 wh_n, wl_n;   // the next step's fragments
-    load_w(0, 0, 0, wh_n, wl_n);
+    f16x8 wh[CF], wl[CF];   // the fragments of the position phase at hand (reloaded, fragment by fragment, behind their last use)
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf) load_w(0, 0, cf, wh[cf], wl[cf]);
     wait_vm<0>();
     __syncthreads();           // the coefficients; chunk 0's LDS-DMA data behind a wait AND a barrier
     convert_chunk(0, 0);
+    WSTAMP(0);
 
     const float tau_b[2] = {tau_b0, tau_b1};
+    // B operand of position pp, tile fragment tf: V' = (P11 + tau_b P12) + tau_a (P21 + tau_b P22) per channel, split into (hi, lo)
+    auto make_b = [&](int pp, int tf, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+        const char* q = smem + tf * (4 * W_PITCH * 128);
+        const float tb = tau_b[pp];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) px[k] = *(const f32x4*)(q + (half ? (ax[pp][k] ^ 16) : ax[pp][k]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaf(fmaf(px[3][e], tb, px[2][e]), tau_a, fmaf(px[1][e], tb, px[0][e]));
+                f16 hh, ll;
+                rs_split(v, hh, ll); h[4 * half + e] = hh; l[4 * half + e] = ll;
+            }
+        }
+    };
     int buf = 0;               // halo buffer of chunk c
     for (int c = 0; c < nch; ++c) {
-        // chunk c + 1 has landed (everything this wave issued except the two fragment loads of the step ahead) ...
-        wait_vm<2>();
+        // chunk c + 1 has landed (everything this wave issued except the 2 CF fragment loads of the phase ahead) ...
+        wait_vm<2 * CF>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // ... and is behind a barrier: convertible.  Chunk c is fp32 for everybody; nobody reads chunk c - 1's buffer any more
         asm volatile("" ::: "memory");
+        WSTAMP(1);
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
         issue_halo(c + 2, buf2);
+        WSTAMP(2);
+        // eight (position, tile fragment) iterations; the B operand of iteration it + 1 is formed (LDS reads + VALU) next to the MFMAs of
+        // iteration it - inside the wave, whatever the other wave of the SIMD is doing
+        f16x8 bh, bl, bhn, bln;
+        if (WABL(2)) { bh = bl = bhn = bln = wh[0]; }
+        if (!WABL(2)) make_b(0, 0, bh, bl);
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const float tb = tau_b[pp];
-            // B operand of the wave's position pp, all four tile fragments: V' = (P11 + tau_b P12) + tau_a (P21 + tau_b P22), split.
-            // One 16-byte half of the four pixels at a time (16 registers in flight), fenced per fragment: left alone the scheduler
-            // hoists all 32 loads of the position and spills.
-            f16x8 bh[4], bl[4];
-#pragma unroll
-            for (int tf = 0; tf < 4; ++tf) {
-                const char* q = smem + tf * (4 * W_PITCH * 128);
-                f16x8 h, l;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f32x4 px[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) px[k] = *(const f32x4*)(q + (half ? (ax[pp][k] ^ 16) : ax[pp][k]));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaf(fmaf(px[3][e], tb, px[2][e]), tau_a, fmaf(px[1][e], tb, px[0][e]));
-                        f16 hh, ll;
-                        rs_split(v, hh, ll); h[4 * half + e] = hh; l[4 * half + e] = ll;
-                    }
-                }
-                bh[tf] = h; bl[tf] = l;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int it = 0; it < 8; ++it) {
+            const int pp = it >> 2, tf = it & 3;
+            if (it < 7 && !WABL(2)) make_b((it + 1) >> 2, (it + 1) & 3, bhn, bln);
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf) {
-                const f16x8 ah = wh_n, al = wl_n;
-                {   // the next step's fragments: pinned here, one step (12 MFMAs + whatever lies between) ahead of their use
-                    const int t1 = pp * CF + cf + 1, q1 = t1 / CF;
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_w(c + (q1 >> 1), q1 & 1, t1 % CF, wh_n, wl_n);
-                    __builtin_amdgcn_sched_barrier(0);
+                const f16x8 as = wh[cf] * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|U| < 32, checked when the weights are packed)
+                if (WABL(1)) { acc[pp][tf][cf][0] += (float)(as[0] * bh[0] + wl[cf][1] * bl[1]); }
+                else {
+                acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh, acc[pp][tf][cf], 0, 0, 0);
+                acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cf], bl, acc[pp][tf][cf], 0, 0, 0);
+                acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cf], bh, acc[pp][tf][cf], 0, 0, 0);
                 }
-                const f16x8 as = ah * (f16)RS_LO_SCALE;   // v_pk_mul_f16: exact (|U| < 32, checked when the weights are packed)
-#pragma unroll
-                for (int tf = 0; tf < 4; ++tf) acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bh[tf], acc[pp][tf][cf], 0, 0, 0);
-#pragma unroll
-                for (int tf = 0; tf < 4; ++tf) acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tf], acc[pp][tf][cf], 0, 0, 0);
-#pragma unroll
-                for (int tf = 0; tf < 4; ++tf) acc[pp][tf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tf], acc[pp][tf][cf], 0, 0, 0);
+                if (tf == 3 && !WABL(8)) load_w(pp ? c + 1 : c, pp ^ 1, cf, wh[cf], wl[cf]);   // last use in this phase: the next phase's fragment
             }
+            bh = bhn; bl = bln;
         }
+        WSTAMP(4);
         // this wave's rows of the next chunk - landed before this chunk's barrier - become fp32 while the other waves compute
-        if (c + 1 < nch) convert_chunk(c + 1, buf1);
+        if (c + 1 < nch && !WABL(4)) convert_chunk(c + 1, buf1);
+        WSTAMP(5);
         {   // the fragment addresses move over to the next halo buffer
             const int flip = buf == 2 ? -2 * W_HBUF : W_HBUF;
 #pragma unroll
@@ -298,6 +313,7 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     const float sy = yy ? -1.f : 1.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last halo requests - zeros past the end - must not land in the exchange buffer)
+    if (!WABL(16)) {
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         __syncthreads();   // all waves done with the LDS (K loop / the previous round's reads)
@@ -382,6 +398,15 @@ __device__ __forceinline__ void wino_body(const IGemmParams& p, char* smem, int 
             if (*tail_flag) rs_gn_tail_finish<512>(p.tail, b, (float*)smem);
         }
     }
+    }
+#ifdef RS_WINO_PHASES
+    WSTAMP(6);
+    ph[7] = tprev - tstart;
+    if (tid == 0 && p.partial) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.partial[(size_t)blockIdx.x * 8 + i] = (float)ph[i];
+    }
+#endif
 }
 
 // one launch: a workgroup = (image, 16 x 16 pixel tile, channel block of 64 - or the 32-channel remainder, on the narrower body)
