@@ -193,9 +193,9 @@ int rs_op_conv2d_bench(const void* x0, const void* w_packed_dev, const float* bi
 int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res,
                        void* y, int B, int H, int W, int Cin, int Cout, int prec, float* ystats_dev, void* stream);
 /* the same layer on the Winograd F(2x2,3x3) kernel (wino.hip; RS_PREC_SPLIT tensors only): U = G g G^T packed on the host, one checked launch;
- * reps > 0: `reps` more launches between two hipEvents, *ms_out = average ms per launch.  ystats_dev (may be null): [B][H*W / 256][Cout][2].
- * Replaces the reference's nn.Conv2d(3x3, padding 1) behind GroupNorm + SiLU (models/unet.py:128-147,186-206; ldm/modules/diffusionmodules/
- * model.py:100-149).  Returns an error when the shape is not eligible (channels % 32, planes that tile by 16 x 16, Cin <= 640). */
+ * reps > 0: `reps` more launches between two hipEvents, *ms_out = average ms per launch.  ystats_dev (may be null): [B][H*W / 128][Cout][2]
+ * (one slab per 8 x 16 pixel tile).  Replaces the reference's nn.Conv2d(3x3, padding 1) behind GroupNorm + SiLU (models/unet.py:128-147,186-206; ldm/modules/diffusionmodules/
+ * model.py:100-149).  Returns an error when the shape is not eligible (Cin % 32, Cout % 64, planes that tile by 8 x 16, Cin <= 640). */
 int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res,
                        void* y, int B, int H, int W, int Cin, int Cout, float* ystats_dev, int reps, float* ms_out, void* stream);
 /* pixels per statistics slab rs_op_conv3x3_halo uses for this shape (0: shape not eligible / no statistics): ystats_dev is

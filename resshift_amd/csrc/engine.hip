@@ -41,6 +41,8 @@ int rs_wino_plan(const IGemmParams* p, int in_dt, int out_dt, int nz);
 int rs_wino_launch(const IGemmParams* p, hipStream_t st);
 size_t rs_wino_weight_bytes(int Cin, int Cout);
 float rs_wino_pack(const float* w_ref, int Cin, int Cout, void* dst);
+int rs_wino_stats_px();
+int rs_wino_tiles(const IGemmParams* p);
 int rs_igemm_split_stats_px(const IGemmParams* p, int splitk);
 int rs_direct_conv_launch(const DirectConvParams* p, int in_dt, int out_dt, hipStream_t st);
 int rs_head_conv_launch(const void* x, int in_dt, const float* coef_dev, const float* w_dev, const float* bias_dev, float* y, int B, int H, int W, int C,
@@ -2226,7 +2228,7 @@ int rs_op_conv3x3_halo(const void* x, const float* coef_dev, int act_in, const f
 
 // The same layer on the Winograd F(2x2,3x3) kernel (wino.hip; split storage only): weights transformed and packed on the host, one checked
 // launch; with reps > 0 the launch is then repeated `reps` times between two hipEvents and *ms_out receives the average milliseconds.
-// `ystats_dev`: [B][H*W / 256][Cout][2] (one slab per 16 x 16 pixel tile).  Fails when the shape is not eligible.
+// `ystats_dev`: [B][H*W / 128][Cout][2] (one slab per 8 x 16 pixel tile).  Fails when the shape is not eligible.
 int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const float* w_ref_host, const float* bias_host, const void* res, void* y,
                        int B, int H, int W, int Cin, int Cout, float* ystats_dev, int reps, float* ms_out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -2242,27 +2244,28 @@ int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const f
     p.out_scale = 1.f; p.splitk = 1; p.xcoef = coef_dev; p.xact = act_in; p.ystats = ystats_dev; p.ystats_ld = Cout;
     int rc = 0;
     float* stamps = nullptr;   // RS_WINO_STAMPS=1 with a -DRS_WINO_PHASES build: per-workgroup phase cycles of wave 0 (see wino.hip), averaged to stderr
-    const int ntile = B * (H / 16) * (W / 16) * ((Cout + 63) / 64);
+    const int ntile = rs_wino_tiles(&p);
     if (const char* ab = getenv("RS_WINO_ABL")) p.dbg = atoi(ab);   // (-DRS_WINO_PHASES builds: timing ablations, wino.hip)
-    if (getenv("RS_WINO_STAMPS")) { (void)hipMalloc((void**)&stamps, (size_t)ntile * 8 * sizeof(float)); (void)hipMemset(stamps, 0, (size_t)ntile * 8 * sizeof(float)); p.partial = stamps; }
+    if (getenv("RS_WINO_STAMPS")) { (void)hipMalloc((void**)&stamps, (size_t)ntile * 16 * sizeof(float)); (void)hipMemset(stamps, 0, (size_t)ntile * 16 * sizeof(float)); p.partial = stamps; }
     if (!rs_wino_plan(&p, RS_F16S, RS_F16S, 1)) rc = fail("shape is not eligible for the wino kernel");
     else {
         rc = rs_wino_launch(&p, st);
         if (rc) fail("wino launch failed");
         if (stamps) {
             (void)hipStreamSynchronize(st);
-            std::vector<float> hs((size_t)ntile * 8);
+            std::vector<float> hs((size_t)ntile * 16);
             (void)hipMemcpy(hs.data(), stamps, hs.size() * sizeof(float), hipMemcpyDeviceToHost);
-            const int nby = (Cout + 63) / 64;
-            double wide[8] = {}, narrow[8] = {}; int nw = 0, nn = 0;
-            for (int t = 0; t < ntile; ++t) {   // (tile ids are XCD-remapped inside the kernel; the stamps are indexed by blockIdx - classify by the total instead)
-                for (int i = 0; i < 8; ++i) wide[i] += hs[(size_t)t * 8 + i];
+            double wide[16] = {}; int nw = 0;
+            for (int t = 0; t < ntile; ++t) {
+                for (int i = 0; i < 16; ++i) wide[i] += hs[(size_t)t * 16 + i];
                 ++nw;
             }
-            (void)narrow; (void)nn; (void)nby;
             static const char* nm[8] = {"prologue", "wait+barrier", "halo issue", "B operand", "MFMA steps", "conversion", "epilogue", "total"};
             fprintf(stderr, "[wino phases] %dx%dx%d %d->%d, mean cycles of wave 0 over %d workgroups:", B, H, W, Cin, Cout, nw);
             for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", nm[i], wide[i] / std::max(1, nw));
+            static const char* nq[6] = {"drain", "barrier-1", "exchange writes", "barrier-2", "transform + stores", "statistics"};
+            fprintf(stderr, "  | epilogue:");
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f", nq[i], wide[8 + i] / std::max(1, nw));
             fprintf(stderr, "\n");
         }
         if (!rc && reps > 0) {

@@ -92,7 +92,7 @@ def conv3x3_halo(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=
 def conv3x3_wino(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=False, reps=0):
     """Winograd F(2x2,3x3) conv (wino.hip): x [B,H,W,Cin] raw split-storage tensor (int32), coef [B,2,Cin] fp32 device (GroupNorm
     affine) applied with `act_in` (0 none / 2 SiLU) inside the kernel; returns [B,H,W,Cout] in split storage (with `want_stats` also
-    the [B, H*W/256, Cout, 2] sums / sums of squares of the stored output; with reps > 0 also the average ms per launch)."""
+    the [B, H*W/128, Cout, 2] sums / sums of squares of the stored output; with reps > 0 also the average ms per launch)."""
     lib = _lib.load()
     B, H, W, Cin = x.shape
     Cout = w_ref.shape[0]
@@ -101,7 +101,7 @@ def conv3x3_wino(x, w_ref, bias=None, coef=None, act_in=0, res=None, want_stats=
     y = torch.empty(B, H, W, Cout, device=x.device, dtype=x.dtype)
     wh, wp = _hostf(w_ref)
     bh, bp = _hostf(bias) if bias is not None else (None, None)
-    st = torch.zeros(B, (H * W) // 256, Cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    st = torch.zeros(B, (H * W) // 128, Cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
     ms = C.c_float(0.0)
     rc = lib.rs_op_conv3x3_wino(x.data_ptr(), coef.data_ptr() if coef is not None else None, act_in, wp, bp,
                                 res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cout,

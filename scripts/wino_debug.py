@@ -48,7 +48,7 @@ def run(B, H, W, Cin, Cout, coef, res, seed=0, kind="rand"):
         ec = err.amax(dim=(0, 2, 3))
         print("   per channel block of 16:", [f"{ec[i:i+16].max().item():.2e}" for i in range(0, Cout, 16)])
         et = err.amax(dim=(0, 1))
-        print("   per 16x16 tile:", [[f"{et[i:i+16, j:j+16].max().item():.1e}" for j in range(0, W, 16)] for i in range(0, H, 16)])
+        print("   per 8x16 tile:", [[f"{et[i:i+8, j:j+16].max().item():.1e}" for j in range(0, W, 16)] for i in range(0, H, 8)])
         e2 = err[0].amax(0)[:16, :16]
         print("   first tile rows (max over channels):")
         for i in range(16):
@@ -58,9 +58,11 @@ def run(B, H, W, Cin, Cout, coef, res, seed=0, kind="rand"):
     print(f"   stats rel err {se:.2e}")
 
 
-run(1, 64, 64, 32, 32, False, False)
-run(1, 64, 64, 32, 32, True, False)
-run(1, 64, 64, 32, 32, False, True)
-run(1, 48, 48, 64, 32, False, False)
+run(1, 16, 16, 32, 64, False, False, kind="center")
+run(1, 16, 16, 32, 64, False, False)
+run(1, 64, 64, 32, 64, True, True)
+run(1, 48, 48, 64, 128, False, False)
 run(4, 32, 32, 160, 160, True, True)
 run(1, 64, 64, 160, 160, False, False)
+run(2, 32, 32, 320, 320, True, True)
+run(2, 64, 64, 128, 256, True, True)

@@ -18,7 +18,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     got = ops.convert(y, ops.F32).cpu().permute(0, 3, 1, 2).double()
     err = (got - ref).abs()
     nb = int((err > 2e-5).sum())
-    tiles = int((err.amax(1).reshape(B, 4, 16, 4, 16).amax(dim=(2, 4)) > 2e-5).sum())
+    tiles = int((err.amax(1).reshape(B, 8, 8, 4, 16).amax(dim=(2, 4)) > 2e-5).sum())
     bad_l += nb > 0
     print(f"iter {it}: max err {err.max().item():.2e}, bad elements {nb}, bad tiles {tiles}", flush=True)
 print("launches with errors:", bad_l)

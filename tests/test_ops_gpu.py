@@ -752,12 +752,12 @@ def test_conv3x3_halo_split_storage(gpu, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
-    (4, 64, 64, 160, 160, True, True),      # the UNet's 64 x 64 level: 5 chunks, channel blocks 64 + 64 + 32
-    (8, 32, 32, 320, 320, True, True),      # 32 x 32 level: 5 blocks of 64
+    (4, 64, 64, 160, 160, True, True),      # the UNet's 64 x 64 level: 5 chunks, all 160 channels in one workgroup (CF = 10)
+    (8, 32, 32, 320, 320, True, True),      # 32 x 32 level: two blocks of 160
     (2, 32, 48, 640, 320, True, False),     # concat input (the coefficient table's limit), non-square plane
-    (1, 128, 128, 128, 128, False, True),   # AE: plain conv (no input transform), residual
-    (3, 16, 16, 32, 32, True, True),        # one chunk, one narrow block, one tile per image (all four borders in every tile)
-    (2, 16, 32, 96, 64, False, False),
+    (1, 128, 128, 128, 128, False, True),   # AE: plain conv (no input transform), residual, CF = 8
+    (3, 8, 16, 32, 64, True, True),         # one chunk, one 64-channel block (CF = 4), one tile per image (all four borders in every tile)
+    (2, 16, 32, 96, 192, False, False),     # three blocks of 64
 ])
 def test_conv3x3_wino_split_storage(gpu, case):
     """wino.hip: Winograd F(2x2,3x3) on (hi, lo) pairs - GroupNorm affine + SiLU applied to the joined value in LDS, V = B^T d B per
