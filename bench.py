@@ -134,6 +134,30 @@ def per_kernel_rooflines(eng):
             for (name, fl, ms, n), pk in zip(eng.profile_families(), fam_peak) if n and ms > 0]
 
 
+def dominant_kernel(shapes, eng):
+    """the launch shape with the largest summed kernel time of the profiled pass, as one roofline row"""
+    if not shapes:
+        return None
+    s = max(shapes, key=lambda r: r["ms"])
+    tf = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
+    fam = eng.FAMILIES[s["family"]] if s["family"] < len(eng.FAMILIES) else str(s["family"])
+    split = "split" in fam
+    return {"kernel": fam, "part": s["part"], "shape": {"M": s["M"], "N": s["N"], "K": s["K"], "z": s["z"]}, "launches_per_step": s["launches"],
+            "ms_per_step": round(s["ms"], 2), "us_per_launch": round(1e3 * s["ms"] / max(1, s["launches"]), 1), "achieved": round(tf, 1),
+            "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS["fp16"], 4),
+            "mfma_issue_frac": round(tf / MFMA_PEAK_TFLOPS["split" if split else "fp16"], 4)}
+
+
+def mfma_ms_by_level(shapes, B):
+    """MFMA-family kernel ms per (part, plane side): M = B * side^2 for the conv / token launches (batched attention GEMMs keep their own M)"""
+    out = {}
+    for s in shapes:
+        side = int(round((s["M"] / max(1, B)) ** 0.5)) if s["z"] == 1 else 0
+        key = f"{s['part']}@{side}" if side and side * side * B == s["M"] else f"{s['part']}@other"
+        out[key] = out.get(key, 0.0) + s["ms"]
+    return {k: round(v, 2) for k, v in sorted(out.items(), key=lambda kv: -kv[1])}
+
+
 def psnr_db(a, b, p2p):
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else float(10 * np.log10(p2p * p2p / mse))
@@ -301,6 +325,7 @@ def main():
         torch.cuda.synchronize()
         st = eng.profile_get()
         per_kernel = per_kernel_rooflines(eng)
+        shapes, parts = eng.profile_shapes()
         eng.profile_enable(False)
         fl = {"fp16": st["flops_f16"], "fp32": st["flops_f32"], "split": st["flops_split"]}
         tot = sum(fl.values())
@@ -309,7 +334,7 @@ def main():
         peak_eff = tot / sum(v / MFMA_PEAK_TFLOPS[k] for k, v in fl.items()) if tot else MFMA_PEAK_TFLOPS["fp16"]
         achieved = tot / (st["igemm_ms"] * 1e-3) / 1e12 if st["igemm_ms"] > 0 else 0.0
         roof = {
-            "bound": "mfma", "policy": pname,
+            "bound": "mfma", "policy": pname, "roofline_schema": 3,   # (3: + dominant_kernel, ms_by_part, mfma_ms_by_level; 2 = round 5: frac against 2.5 PFLOP/s)
             "kernel": "igemm4_kernel<*> (dominant: halo 3x3 conv) / igemm_split_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / "
                       "win_attn_qkv*_kernel / ae_flash_attn*_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS["fp16"], 4),
@@ -325,6 +350,12 @@ def main():
             "algorithmic_gflop_per_image_igemm": round(tot / B / 1e9, 1), "algorithmic_gflop_per_image_total": gflop_per_image,
             "igemm_ms_per_step": round(st["igemm_ms"], 2), "whole_path_tflops": round(gflop_per_image * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
             "dominant_precision": dom,
+            # ONE kernel instantiation - the launch shape with the largest summed kernel time of the pass - with its own fraction:
+            # algorithmic flops of its launches / their hipEvent time / 2.5 PFLOP/s
+            "dominant_kernel": dominant_kernel(shapes, eng),
+            # where the pass goes: wall ms of the reference modules' counterparts, and the MFMA family's kernel ms by plane size
+            "ms_by_part": {k: round(v, 2) for k, v in parts.items()},
+            "mfma_ms_by_level": mfma_ms_by_level(shapes, B),
             # per kernel family (north_star: "per-kernel achieved-fraction-of-roofline"): same hipEvent brackets, grouped
             "per_kernel": per_kernel,
         }

@@ -167,6 +167,11 @@ int rs_profile_get(rs_engine* e, double* out9);
 int rs_profile_families(rs_engine* e, double* out, int cap);
 /* debug trace (tests only): when enabled, the next network call records named intermediate activations
  * (scratch is not recycled while enabled); fetch converts entry i to NCHW fp32 into caller memory. */
+/* text table of the last profiled call: per (part, kernel family, M, N, K) launch shape of the MFMA family - launches, summed kernel ms
+ * (hipEvents on the launch stream), algorithmic flops - and the wall ms of the encoder / UNet / decoder parts (measurement, d of SURVEY 8:
+ * where a pass's time goes per reference module - ldm/modules/diffusionmodules/model.py Encoder / Decoder, models/unet.py UNetModelSwin).
+ * Returns the bytes needed incl. the terminating 0; copies at most cap. */
+int rs_profile_shapes(rs_engine* e, char* buf, int cap);
 int rs_debug_enable(rs_engine* e, int on);
 int rs_debug_count(rs_engine* e);
 int rs_debug_info(rs_engine* e, int i, char* name, int name_cap, int* dims_bchw);

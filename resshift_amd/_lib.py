@@ -94,6 +94,7 @@ SIGNATURES = {
     "rs_profile_enable": (_I, [_P, _I]),
     "rs_profile_get": (_I, [_P, C.POINTER(C.c_double)]),
     "rs_profile_families": (_I, [_P, C.POINTER(C.c_double), _I]),
+    "rs_profile_shapes": (_I, [_P, C.c_char_p, _I]),
     "rs_debug_enable": (_I, [_P, _I]),
     "rs_debug_count": (_I, [_P]),
     "rs_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int)]),

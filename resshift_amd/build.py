@@ -68,5 +68,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_testhooks(verbose: bool = False) -> str:
+    """libresshift_hip_testhooks.so: the same objects with engine.hip recompiled under -DRS_TEST_HOOKS (the RS_FAKE_DEVICE plumbing hook of
+    tests/_fake_device_plumbing.py).  Never loaded by the product: resshift_amd._lib loads libresshift_hip.so unless RESSHIFT_HIP_LIB says otherwise."""
+    build(force=False, verbose=verbose)
+    out = os.path.join(HERE, "libresshift_hip_testhooks.so")
+    stamp = out + ".stamp"
+    dig = _digest() + "+hooks"
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return out
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "engine.hip"]
+    if not all(os.path.exists(o) for o in objs):   # (the library was built elsewhere: compile everything once)
+        os.makedirs(OBJ, exist_ok=True)
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+            list(ex.map(_compile, [s for s in SOURCES if s != "engine.hip"]))
+    hobj = os.path.join(OBJ, "engine_testhooks.o")
+    r = subprocess.run([HIPCC, *FLAGS, "-DRS_TEST_HOOKS", "-c", os.path.join(CSRC, "engine.hip"), "-o", hobj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for engine.hip (-DRS_TEST_HOOKS):\n{r.stderr[-4000:]}")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, hobj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)

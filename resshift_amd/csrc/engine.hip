@@ -283,15 +283,24 @@ struct Exec {
     // the time per distinct shape to stderr
     std::vector<std::string> tag_of;
     std::vector<double> tag_flops;
+    // which network the launches belong to (rs_profile_shapes: "encoder" / "unet" / "decoder") and, profiling passes only, an event at every
+    // change of part: the wall time of the parts between them (every kernel, not just the bracketed MFMA family)
+    const char* part = "";
+    std::vector<std::pair<std::string, hipEvent_t>> part_marks;
+    void enter_part(const char* name) {
+        part = name;
+        if (dry || !prof || !prof->on) return;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        (void)hipEventRecord(ev, st);
+        part_marks.emplace_back(name, ev);
+    }
     void fam_note(int f, double flops, long long M = 0, int N = 0, int K = 0, int nz = 1) {
         fam_flops[f] += flops; ++fam_launches[f];
         if (prof && prof->on) {
             fam_of.push_back((unsigned char)f);
-            static const bool shapes = getenv("RS_PROF_SHAPES") != nullptr;
-            if (shapes) {
-                char b[96]; snprintf(b, sizeof b, "f%d M=%lld N=%d K=%d z=%d", f, M, N, K, nz);
-                tag_of.emplace_back(b); tag_flops.push_back(flops);
-            }
+            char b[128]; snprintf(b, sizeof b, "%s f%d M=%lld N=%d K=%d z=%d", part, f, M, N, K, nz);
+            tag_of.emplace_back(b); tag_flops.push_back(flops);
         }
     }
     void igemm(const IGemmParams& p, int in_dt, int out_dt, int nz, const char* what) {
@@ -390,8 +399,10 @@ struct Exec {
 
 }  // namespace
 
-// RS_FAKE_DEVICE=1 is honoured only where there is NO HIP device (the build container): there the engine's real pass walks its control flow
-// on a host-memory arena while every launch fails - a CPU test compares its bookkeeping with the dry pass.  On a GPU box the variable is ignored.
+// Test hook, compiled ONLY into the test-hooks library (-DRS_TEST_HOOKS: resshift_amd.build.build_testhooks(), loaded by tests/_fake_device_plumbing.py
+// alone - the production libresshift_hip.so does not contain it): with RS_FAKE_DEVICE=1 on a host WITHOUT a HIP device the engine's real pass walks
+// its control flow on a host-memory arena while every launch fails - a CPU test compares its bookkeeping with the dry pass.
+#ifdef RS_TEST_HOOKS
 static bool rs_fake_device() {
     static const bool fake = []() {
         if (!getenv("RS_FAKE_DEVICE")) return false;
@@ -402,6 +413,9 @@ static bool rs_fake_device() {
     }();
     return fake;
 }
+#else
+static constexpr bool rs_fake_device() { return false; }
+#endif
 
 struct rs_engine {
     rs_config cfg;
@@ -429,6 +443,7 @@ struct rs_engine {
     Exec::Prof prof, prof_gn;
     double last_flops[3] = {0.0, 0.0, 0.0}, last_igemm_ms = 0.0, last_igemm_bytes = 0.0, last_gn_ms = 0.0, last_gn_bytes = 0.0;
     double last_fam[Exec::F_COUNT][3] = {};   // flops, ms, launches per kernel family
+    std::string last_shapes;                  // rs_profile_shapes: one line per (part, family, M, N, K) and per part of the last profiled call
     long long last_igemm_launches = 0, last_gn_launches = 0;
     bool debug = false;
     std::vector<std::pair<std::string, View>> trace;
@@ -1459,6 +1474,7 @@ struct rs_engine {
     // lq_feat: optional NHWC view of the (feature-extracted) conditioning; out: NCHW fp32.
     void unet_body(Exec& ex, const float* x, float xscale, const View* lq_feat, const float* lq_nchw, const float* mask_nchw, int Hl, int Wl,
                    float* out, int B, int H, int W, int dt, const float* film) {
+        ex.enter_part("unet");
         const rs_unet_config& u = cfg.unet;
         const int n_in = (int)in_blocks.size(), n_out = (int)out_blocks.size();
         const size_t mk0 = ex.mark();
@@ -1628,6 +1644,7 @@ struct rs_engine {
     // ---------------------------------------------------------------- AE
     // img NCHW fp32 [B,3,H,W] (or NHWC view if `img_nhwc`) -> z NCHW fp32 [B,embed,H/f,W/f]
     void encode_body(Exec& ex, const View& in_nhwc, float* z_nchw, int dt) {
+        ex.enter_part("encoder");
         const rs_ae_config& a = cfg.ae;
         const size_t mk0 = ex.mark();
         ex.pool_off = 0;
@@ -1662,6 +1679,7 @@ struct rs_engine {
     }
     // z NCHW fp32 [B,embed,h,w] -> img NCHW fp32
     void decode_body(Exec& ex, const float* z_nchw, float zscale, float* img, int32_t* idx_out, int B, int h_, int w_, int force_nq, int dt) {
+        ex.enter_part("decoder");
         const rs_ae_config& a = cfg.ae;
         const size_t mk0 = ex.mark();
         ex.pool_off = 0;
@@ -1784,13 +1802,31 @@ struct rs_engine {
                     a[0] += std::max(0.f, ms - overhead); a[1] += 1.0; a[2] += r.tag_flops[i / 2];
                 }
                 std::vector<std::pair<double, std::string>> rows;
+                last_shapes.clear();
                 for (auto& kv : agg) {
                     char b[200]; snprintf(b, sizeof b, "%-40s n=%4.0f  %8.3f ms  %7.1f us/launch  %7.1f TF/s", kv.first.c_str(), kv.second[1], kv.second[0],
                                           1e3 * kv.second[0] / kv.second[1], kv.second[2] / (kv.second[0] * 1e-3) / 1e12);
                     rows.emplace_back(-kv.second[0], b);
+                    char c[200]; snprintf(c, sizeof c, "shape %s n=%.0f ms=%.4f flops=%.6e\n", kv.first.c_str(), kv.second[1], kv.second[0], kv.second[2]);
+                    last_shapes += c;
                 }
                 std::sort(rows.begin(), rows.end());
-                for (auto& rw : rows) fprintf(stderr, "[shapes] %s\n", rw.second.c_str());
+                static const bool shapes = getenv("RS_PROF_SHAPES") != nullptr;
+                if (shapes) for (auto& rw : rows) fprintf(stderr, "[shapes] %s\n", rw.second.c_str());
+            }
+            // wall time of the parts (events at every change of part, the call's end closes the last one)
+            if (!r.part_marks.empty()) {
+                hipEvent_t endev = nullptr;
+                (void)hipEventCreate(&endev); (void)hipEventRecord(endev, st); (void)hipEventSynchronize(endev);
+                std::map<std::string, double> pm; std::vector<std::string> order;
+                for (size_t i = 0; i < r.part_marks.size(); ++i) {
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, r.part_marks[i].second, i + 1 < r.part_marks.size() ? r.part_marks[i + 1].second : endev);
+                    if (!pm.count(r.part_marks[i].first)) order.push_back(r.part_marks[i].first);
+                    pm[r.part_marks[i].first] += ms;
+                }
+                for (auto& nm : order) { char c[96]; snprintf(c, sizeof c, "part %s ms=%.4f\n", nm.c_str(), pm[nm]); last_shapes += c; }
+                (void)hipEventDestroy(endev);
             }
             for (size_t i = 0; i + 1 < prof_gn.used; i += 2) {
                 float ms = 0.f;
@@ -1798,6 +1834,7 @@ struct rs_engine {
                 last_gn_ms += std::max(0.f, ms - overhead);
             }
         }
+        for (auto& pmk : r.part_marks) (void)hipEventDestroy(pmk.second);
         if (r.err) return r.err;
         return 0;
     }
@@ -1918,6 +1955,18 @@ int rs_profile_families(rs_engine* e, double* out, int cap) {
     if (!e || !out || cap < 3 * Exec::F_COUNT) return -1;
     for (int f = 0; f < Exec::F_COUNT; ++f) { out[3 * f] = e->last_fam[f][0]; out[3 * f + 1] = e->last_fam[f][1]; out[3 * f + 2] = e->last_fam[f][2]; }
     return Exec::F_COUNT;
+}
+
+// Text table of the last PROFILED call (rs_profile_enable): one line per distinct launch shape of the MFMA family,
+//   "shape <part> f<family> M=.. N=.. K=.. z=.. n=<launches> ms=<summed kernel ms> flops=<algorithmic flops>"
+// (part = encoder / unet / decoder; family numbering as rs_profile_families), then one line per part, "part <name> ms=<wall ms between the
+// part's first launch and the next part's>" (every kernel of the part, whatever its family).  Returns the length needed (incl. the
+// terminating 0); copies at most cap bytes.
+int rs_profile_shapes(rs_engine* e, char* buf, int cap) {
+    if (!e) return -1;
+    const int need = (int)e->last_shapes.size() + 1;
+    if (buf && cap > 0) { const int n = std::min(cap - 1, need - 1); memcpy(buf, e->last_shapes.data(), n); buf[n] = 0; }
+    return need;
 }
 
 // ---- debug trace (tests only): record named intermediate activations of the next network call

