@@ -179,6 +179,60 @@ def offline_profile(kind: str, precision: str, config: str, B: int):
     return j, None
 
 
+def tiled_main(args):
+    """`--tiled HxW`: throughput of the TILED large-image path (utils/util_image.py:889-979 ImageSpliterTh, sampler.py:186-208,
+    inference_resshift.py:149-161) - one LR image of HxW pixels cut into overlapping `--chop-size` tiles, `chop_bs` tiles per sampler call,
+    overlap-averaged on the GPU.  One JSON line: tiles/s with chop_bs = 1 and batched, output megapixels/s.  (Parity of this path: tests/ -
+    tests/golden/reference_tiled.npz from the reference's own ImageSpliterTh, and the chop-512 tile under the parity policy.)"""
+    from resshift_amd import ResShiftSampler
+    from resshift_amd.config import ConfigNode
+    from resshift_amd.tiling import TileSplitter
+
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda:0")
+    cname = CONFIGS[args.config][0]
+    cfg = to_plain(load_config(cname))
+    up, aep, dp = cfg["model"]["params"], cfg["autoencoder"]["params"], cfg["diffusion"]["params"]
+    H, W = (int(v) for v in args.tiled.lower().split("x"))
+    chop = args.chop_size
+    stride = chop - max(16, chop // 8)   # (the reference's default overlap: chop 512 -> stride 448, inference_resshift.py:54-58)
+    uspec, _ = unet_param_spec(up)
+    sds = {"model": random_state_dict(uspec, seed=1), "autoencoder": random_state_dict(ae_param_spec(aep), seed=2)}
+    conf = ConfigNode(model=ConfigNode(target="models.unet.UNetModelSwin", ckpt_path=None, params=up),
+                      diffusion=ConfigNode(target="models.script_util.create_gaussian_diffusion", params=dp),
+                      autoencoder=ConfigNode(target="ldm.models.autoencoder.VQModelTorch", ckpt_path=None, params=aep))
+    g = torch.Generator().manual_seed(5)
+    y = (torch.rand(1, 3, H, W, generator=g) * 2 - 1).to(dev)
+    sf = int(dp.get("sf", 4))
+    ntiles = len(TileSplitter(y, chop, stride=stride, sf=sf, extra_bs=1))
+    res = {}
+    for bs in sorted({1, min(args.chop_bs, ntiles)}):
+        smp = ResShiftSampler(conf, sf=sf, use_amp=True, chop_size=chop, chop_stride=stride, chop_bs=bs, padding_offset=64, seed=7, state_dicts=sds,
+                              precision=args.precision)
+        out = None
+        ts = []
+        for it in range(1 + args.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = smp.sample_tiled(y, noise_repeat=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        assert tuple(out.shape) == (1, 3, sf * H, sf * W) and torch.isfinite(out).all() and out.abs().max().item() <= 1.0
+        sec = float(np.median(ts[1:]))   # (the first call allocates the arena)
+        res[bs] = {"chop_bs": bs, "seconds_per_image": round(sec, 4), "tiles_per_sec": round(ntiles / sec, 3),
+                   "output_megapixels_per_sec": round(sf * H * sf * W / sec / 1e6, 3), "first_call_s": round(ts[0], 3),
+                   "arena_gib": round(smp.model.engine().arena_bytes() / 2 ** 30, 2)}
+        del smp
+        torch.cuda.empty_cache()
+    best = max(res.values(), key=lambda r: r["tiles_per_sec"])
+    print(json.dumps({"metric": "tiles/sec, tiled large-image path (ImageSpliterTh-equivalent on the GPU), 15 steps", "value": best["tiles_per_sec"],
+                      "unit": "tiles/s", "n_gpus": 1, "steps": args.steps, "warmup": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": f"{args.precision} policy", "data": "synthetic",
+                      "config": {"workload": f"{cname}: one {H}x{W} LR image -> {sf * H}x{sf * W}, chop_size {chop}, stride {stride}, {ntiles} tiles",
+                                 "precision_policy": args.precision},
+                      "by_chop_bs": list(res.values())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +253,15 @@ def main():
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the PyTorch-ROCm autocast leg")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the ms_per_unet_step leg (profiling passes: the trace / PMC files must hold whole passes only)")
     ap.add_argument("--no-reference-modules", action="store_true", help="baseline legs on the oracle's restatement even when oracle/_ref is present")
+    ap.add_argument("--tiled", default=None, metavar="HxW", help="time the tiled large-image path on one HxW LR image instead of the batch workload (one GPU)")
+    ap.add_argument("--chop-size", type=int, default=128, help="--tiled: LR tile side (the reference's default for x4 models is 512)")
+    ap.add_argument("--chop-bs", type=int, default=8, help="--tiled: tiles per sampler call of the batched leg (chop_bs = 1 is always timed too)")
     args = ap.parse_args()
+
+    if args.tiled:
+        if args.gpus != 1:
+            raise SystemExit("[bench] --tiled times one image on one GPU")
+        return tiled_main(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not started by a launcher: become one (one process per GPU, sampler.py:66-77).  The children see WORLD_SIZE and skip this.

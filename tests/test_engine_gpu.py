@@ -978,6 +978,36 @@ def test_bench_launches_its_own_ranks(gpu):
         assert r2.returncode != 0 and "refused" in (r2.stderr + r2.stdout)
 
 
+def test_bench_two_gpus_over_rccl(gpu):
+    """First contact with RCCL (sampler.py:66-77,233-234,273-277,290-291): on a box with >= 2 GPUs `bench.py --gpus 2` must come
+    up under backend nccl (= RCCL on ROCm) with one device per rank, broadcast the weight blob ONCE, and give both ranks the same throughput.
+    Skipped on the one-GPU boxes this suite usually runs on - so that the first multi-GPU node produces a curve instead of a surprise."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (backend nccl binds one device per rank)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RESSHIFT_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-profile-pass", "--no-unet-step"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    rk = line["ranks"]
+    assert line["n_gpus"] == 2 and rk["world_size"] == 2 and rk["backend"] == "nccl", rk
+    assert rk.get("rccl_version"), rk                                     # the communicator really came up
+    assert rk["weight_broadcast_bytes"] > 100e6 and rk.get("weight_broadcasts", 1) == 1
+    ips = [q["images_per_sec"] for q in rk["per_rank"]]
+    assert len(ips) == 2 and abs(ips[0] - ips[1]) <= 0.05 * max(ips), ips   # no rank waits for the other: zero steady-state collectives
+    assert line["scaling"] == "weak" and line["value"] > 1.8 * min(ips) > 0
+
+
 def test_tiled_path_one_side_shorter_than_the_tile(gpu):
     """an input with one side <= chop_size and the other larger (e.g. 480x640 with chop 512; here 12x40 with 16-pixel
     tiles): the slice clamps the tile AND its canvas window, exactly like the reference's slice assignment
