@@ -124,7 +124,7 @@ def per_kernel_rooflines(eng):
     arithmetic they run (split storage: three fp16 MFMAs per product -> 2500 / 3)"""
     fam_peak = [MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"],
                 MFMA_PEAK_TFLOPS["fp32"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["split"],
-                MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"]]
+                MFMA_PEAK_TFLOPS["fp16"], MFMA_PEAK_TFLOPS["split"], MFMA_PEAK_TFLOPS["split"]]
     # `frac` is SURVEY.md §8(d)'s: ALGORITHMIC flops / time / the dense fp16 MFMA peak (2.5 PFLOP/s) - a split-storage kernel issues three
     # MFMAs per algorithmic product and is not credited for the two extra ones; `mfma_issue_frac` is the matrix-pipe utilisation (the
     # same figure against the peak of the arithmetic the kernel actually issues: 2500 / 3 for split storage, 157.3 for fp32 MFMA)
@@ -135,10 +135,17 @@ def per_kernel_rooflines(eng):
 
 
 def dominant_kernel(shapes, eng):
-    """the launch shape with the largest summed kernel time of the profiled pass, as one roofline row"""
+    """the kernel instantiation + grid (family, M, N; all its K) with the largest summed kernel time of the profiled pass, as one roofline row"""
     if not shapes:
         return None
-    s = max(shapes, key=lambda r: r["ms"])
+    # one kernel INSTANTIATION on one grid = (family, M, N): its launches differ only in the K loop's length (the input channel count)
+    groups = {}
+    for r in shapes:
+        g = groups.setdefault((r["part"], r["family"], r["M"], r["N"], r["z"]), {"ms": 0.0, "flops": 0.0, "launches": 0, "K": []})
+        g["ms"] += r["ms"]; g["flops"] += r["flops"]; g["launches"] += r["launches"]; g["K"].append(r["K"])
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[key]
+    s = {"part": key[0], "family": key[1], "M": key[2], "N": key[3], "z": key[4], "K": sorted(g["K"]), "ms": g["ms"], "flops": g["flops"], "launches": g["launches"]}
     tf = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
     fam = eng.FAMILIES[s["family"]] if s["family"] < len(eng.FAMILIES) else str(s["family"])
     split = "split" in fam

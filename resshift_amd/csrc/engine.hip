@@ -164,6 +164,7 @@ struct ConvW {
     // fragment-major copies for the fused window-attention kernels (add_frag_copies): [16-row block][32-wide k step][lane] x 16 B (fp16;
     // split: 1 KB of hi then 1 KB of lo per block and k step), so that a wave's A-operand fragment is ONE contiguous 1 KB read
     void* wh_frag = nullptr; void* ws_frag = nullptr;
+    void* ww = nullptr;   // Winograd F(2x2,3x3) form of a 3x3 conv's split weights (wino.hip: rs_wino_pack order), packed only with RS_WINO=1
     bool direct = false;
     int idx = -1;   // position in rs_engine::big_w (per-layer "|w| >= 30" flags, see there)
     const void* w_for(int dt) const { return dt == RS_F16 ? wh : (dt == RS_F16S ? ws : wf); }
@@ -275,7 +276,7 @@ struct Exec {
     double igemm_bytes = 0.0;            // algorithmic (compulsory) HBM bytes: source tensor + weights + output (+ residual), once each
     long long igemm_launches = 0;
     // per kernel family of the MFMA path (rs_profile_families): algorithmic FLOPs, launches, and the family of every bracket
-    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_AEFLASH, F_AEFLASH_S, F_COUNT };
+    enum Fam { F_HALO16 = 0, F_HALO_SPLIT, F_IGEMM16, F_IGEMM_SPLIT, F_IGEMM32, F_WINATTN, F_SWINMLP, F_WINATTN_S, F_SWINMLP_S, F_AEFLASH, F_AEFLASH_S, F_WINO_S, F_COUNT };
     double fam_flops[F_COUNT] = {};
     long long fam_launches[F_COUNT] = {};
     std::vector<unsigned char> fam_of;   // family of bracket k (profiling pass only)
@@ -308,8 +309,9 @@ struct Exec {
         igemm_flops[in_dt == RS_F16 ? 0 : (in_dt == RS_F16S ? 2 : 1)] += 2.0 * (double)p.M * (double)p.Cout * (double)Kall * (double)nz;
         {
             int tw, bc;
-            const bool halo = rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw, &bc) != 0;
-            const int f = in_dt == RS_F16 ? (halo ? F_HALO16 : F_IGEMM16) : (in_dt == RS_F16S ? (halo ? F_HALO_SPLIT : F_IGEMM_SPLIT) : F_IGEMM32);
+            const bool wino = rs_wino_plan(&p, in_dt, out_dt, nz) != 0;
+            const bool halo = !wino && rs_igemm4_pick(&p, in_dt, out_dt, nz, &tw, &bc) != 0;
+            const int f = wino ? F_WINO_S : (in_dt == RS_F16 ? (halo ? F_HALO16 : F_IGEMM16) : (in_dt == RS_F16S ? (halo ? F_HALO_SPLIT : F_IGEMM_SPLIT) : F_IGEMM32));
             fam_note(f, 2.0 * (double)p.M * (double)p.Cout * (double)Kall * (double)nz, p.M, p.Cout, Kall, nz);
         }
         {
@@ -549,6 +551,16 @@ struct rs_engine {
                                 o[(size_t)co * 2 * K + k] = h;
                                 o[(size_t)co * 2 * K + K + k] = l;
                             }
+                });
+            // Winograd F(2x2,3x3) form (wino.hip).  RS_WINO=0 when the engine is CREATED switches it off (the blob layout depends on it: every rank
+            // of a run has to agree, like RS_UPFOLD).  Only the layers whose whole output fits 160-channel blocks (the UNet's 160 / 320-channel ResBlock
+            // convs, + 200 MB of blob): on those the kernel measured 1.07 - 1.12 x the halo kernel - 243.6 -> 238.6 ms per parity pass on one box,
+            // two pairs - on the autoencoder's 128 / 256 / 512-channel layers 0.92 - 1.04 x (profiles/r6_wino_bench.txt).
+            static const bool wino_on = []() { const char* e = getenv("RS_WINO"); return !(e && e[0] == '0'); }();
+            if (wino_on && cfg.enable_split && KH == 3 && KW == 3 && (Cin % 32) == 0 && Cin <= 640 && (Cout % 160) == 0 && Cout <= 320)
+                c.ww = blob.add(rs_wino_weight_bytes(Cin, Cout), [&](char* dst) {
+                    const float* w = get(); if (!w) return;
+                    if (!(rs_wino_pack(w, Cin, Cout, dst) < 30.0f)) big_w[cidx] = 1;   // (the kernel scales the hi fragment by 2^11 in fp16, like the halo kernel)
                 });
             if (cfg.enable_f32)
                 c.wf = blob.add(np * 4, [&](char* dst) {
@@ -973,16 +985,26 @@ struct rs_engine {
         p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Cout = w.Cout; p.ldy = y.ld; p.ldres = res ? res->ld : 0;
         p.M = y.B * y.H * y.W; p.Ktot = w.KH * w.KW * (x.C + C1); p.act = act; p.out_scale = out_scale;
         p.splitk = 1;
+        p.ww = (x.dt == RS_F16S && !x1) ? w.ww : nullptr;
         return p;
     }
     // true when this 3x3 conv runs on the halo kernel (igemm4.hip), which can apply a GroupNorm affine + SiLU to its input
     // while the halo tile sits in LDS: the producer's raw output is read, the GroupNorm apply pass disappears
     // (`sk`: the halo kernel's own split-K factor for this launch - the small planes of the 16 x 16 / 8 x 8 levels run as split-K
     // slices over the stage sequence, igemm4_kernel.h; `seg`: its tile geometry, 8 = four 8 x 8 images per tile)
-    bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res, int* sk = nullptr, int* seg = nullptr) const {
+    // (`folded`: the launch will carry a folded 1x1 shortcut - only the halo kernel does that; `wino`: out, the Winograd kernel takes it)
+    bool halo_conv(const ConvW& w, const View& x, const View& y, const View* res, int* sk = nullptr, int* seg = nullptr, bool folded = false,
+                   bool* wino = nullptr) const {
+        if (wino) *wino = false;
         if (w.direct || (x.dt != RS_F16 && x.dt != RS_F16S) || y.dt != x.dt || x.C != w.CinP) return false;
         if (x.dt == RS_F16S && big(w)) return false;   // |w| >= 30: no 2^11 scaling of the hi fragment - the generic split kernel takes it (conv(): IGemmParams::no_halo)
         const IGemmParams p = conv_params(w, x, nullptr, y, 1, 1, 1, 1, 0, res, 1.f);
+        if (!folded && rs_wino_plan(&p, x.dt, y.dt, 1)) {   // same fusions as the halo kernel (input transform, statistics, tail), its own tiles
+            if (sk) *sk = 1;
+            if (seg) *seg = 0;
+            if (wino) *wino = true;
+            return true;
+        }
         int tw, bc, sg = 0, k = 1;
         if (!rs_igemm4_plan(&p, x.dt, y.dt, 1, &tw, &bc, &sg, &k)) return false;
         if (sk) *sk = k;
@@ -1000,7 +1022,7 @@ struct rs_engine {
             const int M = y.B * y.H * y.W;
             int sk4 = 1;
             // the halo kernel plans its own split-K (slices of the stage sequence); everything else asks the generic planner
-            if (!x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res, &sk4)) splitk = sk4;
+            if (!x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res, &sk4, nullptr, skw != nullptr)) splitk = sk4;
             else splitk = rs_igemm_splitk_plan(M, w.Cout, w.KH * w.KW * (x.C + C1), x.dt);
             if (splitk > 1) partial = (float*)ex.raw((size_t)splitk * M * w.Cout * sizeof(float));
         }
@@ -1031,9 +1053,9 @@ struct rs_engine {
             p.no_halo = (x.dt == RS_F16S && big(w)) ? 1 : 0;   // (the launcher picks the kernel from the parameter block: tell it what halo_conv() decided)
             p.splitk = splitk; p.partial = partial;
             p.xcoef = xcoef; p.xact = xact;
-            if (skw) { p.sx = skx->p; p.sw = skw->w_for(x.dt); p.sbias = skw->bias; p.sC = skx->C; p.sld = skx->ld; }   // folded 1x1 shortcut (skip_fold())
+            if (skw) { p.sx = skx->p; p.sw = skw->w_for(x.dt); p.sbias = skw->bias; p.sC = skx->C; p.sld = skx->ld; p.ww = nullptr; }   // folded 1x1 shortcut (skip_fold()): the halo kernel's
             if (y.st) {   // statistics for the consuming GroupNorm: the halo kernel's or the generic split kernel's epilogue (or their split-K reduce)
-                const bool halo = !x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res);
+                const bool halo = !x1 && w.KH == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && up == 1 && halo_conv(w, x, y, res, nullptr, nullptr, skw != nullptr);
                 if (halo || (!x1 && x.dt == RS_F16S && y.dt == RS_F16S)) { p.ystats = y.st; p.ystats_ld = y.stld; }
                 else { ex.err = -3; g_err = "output statistics requested from a conv whose kernel cannot produce them"; return; }
                 (void)ex.fill_tail(y.st_prod, y.B, p.tail);   // ... and that GroupNorm's coefficients too (gn_tail.h)
@@ -1062,14 +1084,14 @@ struct rs_engine {
         if (X.dt == RS_F16S && (big(r.skip) || big(r.c2))) return false;
         if (!r.skip.w_for(X.dt) || r.skip.KH != 1 || X.C != r.skip.CinP || (X.C % 32) || (X.ld % 8) || X.H != Y.H || X.W != Y.W) return false;
         int sk = 1, seg = 0;
-        return halo_conv(r.c2, h1, Y, nullptr, &sk, &seg) && sk == 1 && seg == 0;
+        return halo_conv(r.c2, h1, Y, nullptr, &sk, &seg, true) && sk == 1 && seg == 0;   // (the HALO kernel's plan: the fold - a GEMM launch saved - beats the Winograd kernel's 10 %)
     }
     // Attach a statistics buffer to a tensor that is about to be produced by conv `w` from `x` (+res) IF its kernel can leave them: the halo
     // kernel (one partial set per 256- or 128-pixel tile of one image), the generic split-storage kernel (RS_GN_GEN_STATS, default on: one
     // set per 128- / 64-pixel tile), or - split-K launches of either - the reduce kernel (slabs of 256 pixels / the whole small image).
     // The buffer lives in the coefficient pool (reset per network body), so a block's output may carry it to whoever consumes it later
     // (the next block, the decoder's concatenation).
-    void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res, int stride = 1, int pad = 1, int up = 1) {
+    void want_stats(Exec& ex, const ConvW& w, const View& x, View& y, const View* res, int stride = 1, int pad = 1, int up = 1, bool folded = false) {
         static const bool on = []() { const char* e = getenv("RS_GN_EPI_STATS"); return !(e && e[0] == '0'); }();
         static const bool gen = []() { const char* e = getenv("RS_GN_GEN_STATS"); return !(e && e[0] == '0'); }();
         const int HW = y.H * y.W;
@@ -1077,7 +1099,8 @@ struct rs_engine {
         if (!on || ex.dbg || w.direct) return;
         const IGemmParams pp = conv_params(w, x, nullptr, y, stride, pad, pad, up, 0, res, 1.f);
         int spx = 0;
-        if (w.KH == 3 && stride == 1 && pad == 1 && up == 1 && halo_conv(w, x, y, res)) spx = rs_igemm4_stats_px(&pp, x.dt);
+        bool wino = false;
+        if (w.KH == 3 && stride == 1 && pad == 1 && up == 1 && halo_conv(w, x, y, res, nullptr, nullptr, folded, &wino)) spx = wino ? rs_wino_stats_px() : rs_igemm4_stats_px(&pp, x.dt);
         else if (gen && x.dt == RS_F16S && y.dt == RS_F16S && x.C == w.CinP)
             spx = rs_igemm_split_stats_px(&pp, rs_igemm_splitk_plan(pp.M, w.Cout, w.KH * w.KW * x.C, x.dt));
         if (spx <= 0 || (HW % spx)) return;
@@ -1091,7 +1114,7 @@ struct rs_engine {
     void gn_silu_conv3(Exec& ex, const GNW& g, const ConvW& w, const View& X, const View& Y, float eps, const float* film, const View* res,
                        const ConvW* skw = nullptr, const View* skx = nullptr) {
         static const bool fold = []() { const char* e = getenv("RS_GN_CONV_FOLD"); return !(e && e[0] == '0'); }();
-        if (fold && !ex.dbg && halo_conv(w, X, Y, res)) {
+        if (fold && !ex.dbg && halo_conv(w, X, Y, res, nullptr, nullptr, skw != nullptr)) {
             const float* coef = gn_coef(ex, g, X, eps, film);
             conv3(ex, w, X, Y, res, 0, coef, RS_ACT_SILU, skw, skx);
             return;
@@ -1190,7 +1213,7 @@ struct rs_engine {
         ex.tr("conv1", h1);
         const float* film = film_row ? film_row + r.film_off : nullptr;
         if (skip_fold(ex, r, X, h1, Y)) {
-            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr);
+            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr, 1, 1, 1, true);
             gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-5f, film, nullptr, &r.skip, &X);
         } else if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
@@ -1210,7 +1233,7 @@ struct rs_engine {
         want_stats(ex, r.c1, X, h1, nullptr);
         gn_silu_conv3(ex, r.n1, r.c1, X, h1, 1e-6f, nullptr, nullptr);
         if (skip_fold(ex, r, X, h1, Y)) {
-            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr);
+            if (out_stats) want_stats(ex, r.c2, h1, Y, nullptr, 1, 1, 1, true);
             gn_silu_conv3(ex, r.n2, r.c2, h1, Y, 1e-6f, nullptr, nullptr, &r.skip, &X);
         } else if (r.has_skip) {
             View sk = ex.T(X.B, X.H, X.W, r.Cout, X.dt);
@@ -2294,7 +2317,8 @@ int rs_op_conv3x3_wino(const void* x, const float* coef_dev, int act_in, const f
     int rc = 0;
     float* stamps = nullptr;   // RS_WINO_STAMPS=1 with a -DRS_WINO_PHASES build: per-workgroup phase cycles of wave 0 (see wino.hip), averaged to stderr
     const int ntile = rs_wino_tiles(&p);
-    if (const char* ab = getenv("RS_WINO_ABL")) p.dbg = atoi(ab);   // (-DRS_WINO_PHASES builds: timing ablations, wino.hip)
+    p.dbg = 64;   // (an op-level entry: no fill-the-chip threshold)
+    if (const char* ab = getenv("RS_WINO_ABL")) p.dbg |= atoi(ab);   // (-DRS_WINO_PHASES builds: timing ablations, wino.hip)
     if (getenv("RS_WINO_STAMPS")) { (void)hipMalloc((void**)&stamps, (size_t)ntile * 16 * sizeof(float)); (void)hipMemset(stamps, 0, (size_t)ntile * 16 * sizeof(float)); p.partial = stamps; }
     if (!rs_wino_plan(&p, RS_F16S, RS_F16S, 1)) rc = fail("shape is not eligible for the wino kernel");
     else {

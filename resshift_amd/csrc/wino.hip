@@ -422,8 +422,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
             WQ(12);
         }
         if (ystats) {
-            // per-channel sums of the tile in a fixed order: every thread parks its 8 + 8 partials, then NO x 8 threads add the 32 (tile, row)
-            // contributions of their channel in index order
+            // per-channel sums of the tile in a fixed order: every thread parks its 8 + 8 partials, then the 32 (tile, row) contributions of a
+            // channel are added in index order
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -435,11 +435,24 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (tid < NO * 8) {
-                const int o = tid >> 3, e = tid & 7;
+            // (two levels: four threads per channel add eight contributions each, then one adds the four - a fixed order; the one-level form was a
+            // serial chain of 32 LDS round trips on 80 threads while 432 waited: 2.9 k of the epilogue's 28 k cycles, twice)
+            float* sb2 = sb + 512 * 16;
+            if (tid < NO * 8 * 4) {
+                const int part = tid / (NO * 8), ch = tid - part * (NO * 8);
+                const int o = ch >> 3, e = ch & 7;
                 float a = 0.f, q = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) { a += sb[(o + NO * k) * 16 + e]; q += sb[(o + NO * k) * 16 + 8 + e]; }
+#pragma unroll
+                for (int k = 8 * part; k < 8 * part + 8; ++k) { a += sb[(o + NO * k) * 16 + e]; q += sb[(o + NO * k) * 16 + 8 + e]; }
+                sb2[(part * NO * 8 + ch) * 2] = a; sb2[(part * NO * 8 + ch) * 2 + 1] = q;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tid < NO * 8) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int part = 0; part < 4; ++part) { a += sb2[(part * NO * 8 + tid) * 2]; q += sb2[(part * NO * 8 + tid) * 2 + 1]; }
                 float* dst = ystats + (((long long)b * (tyb_n * txb_n) + tyb * txb_n + txb) * p.ystats_ld + n0 + half * CFH * 16 + tid) * 2;
                 if (tail_on) rs_pub_pair(dst, a, q);
                 else { dst[0] = a; dst[1] = q; }
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
         // barrier - wave 0 draws the ticket)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        unsigned* const tail_flag = (unsigned*)(smem + 512 * 64);
+        unsigned* const tail_flag = (unsigned*)(smem + 65536);   // (behind the statistics scratch and the finish's 2 C + 2 groups floats)
         if (wave == 0) { const bool last = rs_gn_tail_arrive(p.tail, b); if (lane == 0) *tail_flag = last ? 1u : 0u; }
         __syncthreads();
         if (*tail_flag) rs_gn_tail_finish<512>(p.tail, b, (float*)smem);
@@ -529,7 +542,7 @@ extern "C" int rs_wino_plan(const IGemmParams* pp, int in_dt, int out_dt, int nz
     if ((p.C0 % 32) || p.C0 > W_MAXCIN || (p.ld0 % 8) || (p.Cout % (16 * w_cf_of(p.Cout))) || (p.ldy % 8) || (p.res && (p.ldres % 8))) return 0;
     if ((p.Ho % W_TH) || (p.Wo % W_TW) || p.splitk > 1) return 0;
     const long long tiles = (long long)p.B * (p.Ho / W_TH) * (p.Wo / W_TW) * (p.Cout / (16 * w_cf_of(p.Cout)));
-    return tiles >= min_tiles ? 1 : 0;
+    return (tiles >= min_tiles || (p.dbg & 64)) ? 1 : 0;   // (dbg bit 6: the op-level test entry runs shapes that do not fill the chip)
 }
 
 // pixels per statistics slab of a wino launch (one slab per 8 x 16 pixel tile); workgroups of a launch

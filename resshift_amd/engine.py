@@ -284,7 +284,8 @@ class Engine:
                 "igemm2 / igemm_kernel<float> (implicit GEMM, exact fp32)", "win_attn_qkv_kernel (fused qkv + window attention + proj)",
                 "swin_mlp_kernel (fused fc1 + GELU + fc2)", "win_attn_qkv_split_kernel (fused qkv + window attention + proj, split storage)",
                 "swin_mlp_split_kernel (fused fc1 + GELU + fc2, split storage)", "ae_flash_attn_kernel (streaming AE mid-block attention, fp16)",
-                "ae_flash_attn_split_kernel (streaming AE mid-block attention, split storage)")
+                "ae_flash_attn_split_kernel (streaming AE mid-block attention, split storage)",
+                "wino_kernel (Winograd F(2x2,3x3) 3x3 conv, split storage; RS_WINO=1)")
 
     def profile_families(self):
         """per kernel family of the MFMA path: [(name, algorithmic FLOPs, kernel ms, launches)] of the last native call"""
