@@ -173,7 +173,7 @@ def psnr_db(a, b, p2p):
 def offline_profile(kind: str, precision: str, config: str, B: int):
     """digest-stamped rocprofv3 results of THIS command collected offline (scripts/collect_traffic.py / collect_gn_trace.py) - or
     (None, why) when the file is missing, was measured on other kernel sources, or for another workload"""
-    path = os.path.join(ROOT, "profiles", f"r5_{kind}_{precision}.json")
+    path = os.path.join(ROOT, "profiles", f"r6_{kind}_{precision}.json")
     if not (config == "realsr" and B == 32):
         return None, "offline rocprofv3 files exist for the default workload only"
     if not os.path.exists(path):
@@ -404,7 +404,7 @@ def main():
         achieved = tot / (st["igemm_ms"] * 1e-3) / 1e12 if st["igemm_ms"] > 0 else 0.0
         roof = {
             "bound": "mfma", "policy": pname, "roofline_schema": 3,   # (3: + dominant_kernel, ms_by_part, mfma_ms_by_level; 2 = round 5: frac against 2.5 PFLOP/s)
-            "kernel": "igemm4_kernel<*> (dominant: halo 3x3 conv) / igemm_split_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / "
+            "kernel": "igemm4_kernel<*> (halo 3x3 conv) / wino_kernel<*> (Winograd 3x3 conv) / igemm_split_kernel<*> / igemm2_kernel<*> / igemm3_kernel<*> / igemm_kernel<*> + swin_mlp*_kernel / "
                       "win_attn_qkv*_kernel / ae_flash_attn*_kernel (MFMA implicit-GEMM family incl. the fused Swin kernels and the streaming autoencoder attention)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS["fp16"], 4),
             "frac_note": "SURVEY.md 8(d): algorithmic flops (2*M*N*K of the launches of the MFMA family) / their hipEvent time / 2.5 PFLOP/s dense fp16; "

@@ -639,7 +639,7 @@ struct rs_engine {
     // (the 8 x 8 -> 16 x 16 and 16 x 16 -> 32 x 32 steps at batch 32 do not: they keep the folded-address form).
     bool upfold_ok(const Exec& ex, const ConvW (&upf)[4], const View& x, const View& y) const {
         if (ex.dbg || x.dt != y.dt || (x.dt != RS_F16 && x.dt != RS_F16S) || y.H != 2 * x.H || y.W != 2 * x.W || x.C != upf[0].CinP) return false;
-        if (!upf[0].w_for(x.dt)) return false;
+        if (!upf[0].w_for(x.dt) || (x.ld % 8) || (y.ld % 8)) return false;   // (the scattered-row launches' alignment preconditions)
         // (measured, profiles/r5_upfold_ab.txt: with the 16 -> 32 and 8 -> 16 steps as well - 8192 / 2048 low-resolution pixels at batch 32, four
         // launches that cannot fill the chip each - the pass is 0.9 ms slower than with the 32 -> 64 step alone)
         return (long long)x.B * x.H * x.W >= 16384;
@@ -1336,7 +1336,8 @@ struct rs_engine {
             // raw input = its shortcut), the product matrix below the scaled-fragment limit.  RS_UNEMBED_FOLD=0: the 1x1 conv as a launch.
             static const bool unfold_on = []() { const char* v = getenv("RS_UNEMBED_FOLD"); return !(v && v[0] == '0'); }();
             const bool unfold = unfold_on && fuse_mlp && fold2 && X.dt == RS_F16S && &s == &b.blocks.back() && b.has_unfold && b.unfold.ws &&
-                                !big(b.unfold) && Y.dt == RS_F16S && Y.C == b.C && rs_swin_mlp_split_unembed_supported(E, s.fc1.Cout, b.C);
+                                !big(b.unfold) && Y.dt == RS_F16S && Y.C == b.C && rs_swin_mlp_split_unembed_supported(E, s.fc1.Cout, b.C) &&
+                                (Y.ld % 8) == 0 && (e2.ld % 8) == 0;   // (the launcher's alignment preconditions: an unaligned view falls back to the separate 1x1 conv instead of failing the pass - ADVICE r5)
             if (unfold) {
                 Y.st = nullptr; Y.st2 = nullptr; Y.st_prod = -1;
                 if (out_stats && sstats && HWt % 128 == 0 && Mtok % 128 == 0) {   // statistics (+ tail) for the GroupNorm that consumes the layer's output

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
     // ---- this wave's positions
     const int pi = wave >> 1, jp = wave & 1;
     const float tau_a = w_tau(pi);
-    const float tau_b[2] = {w_tau(2 * jp), w_tau(2 * jp + 1)};
+    // (which of the wave's two positions is worked on first alternates between workgroups - `pflip`: one more way in which workgroups that run in
+    // step do not ask the L2 for the same weight lines at the same moment)
+    const int pflip = (int)((blockIdx.x >> 3) / (unsigned)max(1, min(p.C0 / 32, 1024 / p.Cout))) & 1;
+    const float tau_b[2] = {w_tau(2 * jp + pflip), w_tau(2 * jp + (1 ^ pflip))};
     const int a1 = w_first(pi), a2 = w_second(pi);
 
     // ---- halo row -> source pixel
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
     auto load_w = [&](int c, int pp, int cf, int ds, f16x8& h, f16x8& l) __attribute__((always_inline)) {
         const int t = pp * CF + cf + ds, q = t / CF;
         const int cc = chunk_of(min(c + (q >> 1), nch - 1));   // (the requests behind the last step re-read the last chunk)
-        const char* src = wbase + (q & 1) * wpos_step + (cc * CF + t % CF) * 2048 + wvl;
+        const char* src = wbase + ((q & 1) ^ pflip) * wpos_step + (cc * CF + t % CF) * 2048 + wvl;
         h = *(const f16x8*)src; l = *(const f16x8*)(src + 1024);
     };
 
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
         const int tx = lane & 7, tyl = (lane >> 3) & 1, g = lane >> 4;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            const int j = 2 * jp + pp, b1 = w_first(j), b2 = w_second(j);
+            const int j = 2 * jp + (pp ^ pflip), b1 = w_first(j), b2 = w_second(j);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int a = (k & 2) ? a2 : a1, bb = (k & 1) ? b2 : b1;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
             for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
                 for (int cq = 0; cq < CFH; ++cq)
-                    *(f32x4*)(smem + ((4 * pi + 2 * jp + pp) * 16 + (lane & 15)) * TS + (cq * 16 + 4 * (lane >> 4)) * 4) = acc[pp][tf][half * CFH + cq];
+                    *(f32x4*)(smem + ((4 * pi + 2 * jp + (pp ^ pflip)) * 16 + (lane & 15)) * TS + (cq * 16 + 4 * (lane >> 4)) * 4) = acc[pp][tf][half * CFH + cq];
             // residual rows of this thread's two pixels, requested in front of the barrier
             const int ty = 2 * tf + ((tl >> 3) & 1), tx = tl & 7;
             const long long m0 = ((long long)b * p.Ho + y0 + 2 * ty + yy) * p.Wo + x0 + 2 * tx;

@@ -27,7 +27,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from resshift_amd import build as _b  # noqa: E402
 
-KEYS = ("igemm", "swin_mlp", "win_attn", "ae_flash")
+KEYS = ("igemm", "wino_kernel", "swin_mlp", "win_attn", "ae_flash")
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(set)
 dur_ns = defaultdict(dict)   # kernel -> dispatch -> duration of that dispatch in THIS (counter-collecting) pass

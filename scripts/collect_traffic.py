@@ -8,7 +8,7 @@ import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from resshift_amd import build as _b  # kernel-source digest: bench.py ignores the file when the sources have changed since
 
-def total(path, counter, keys=("igemm", "swin_mlp", "win_attn_qkv", "ae_flash_attn")):
+def total(path, counter, keys=("igemm", "wino_kernel", "swin_mlp", "win_attn_qkv", "ae_flash_attn")):
     s = 0.0; n = 0
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in keys):
@@ -17,7 +17,7 @@ def total(path, counter, keys=("igemm", "swin_mlp", "win_attn_qkv", "ae_flash_at
 
 f, nf = total(sys.argv[1], "FETCH_SIZE")
 w, nw = total(sys.argv[2], "WRITE_SIZE")
-out = {"kernel_family": "igemm*_kernel + swin_mlp*_kernel + win_attn_qkv*_kernel + ae_flash_attn_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
+out = {"kernel_family": "igemm*_kernel + wino_kernel + swin_mlp*_kernel + win_attn_qkv*_kernel + ae_flash_attn_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_per_launch": 2.0 * f * 1024 / max(1, nf), "write_bytes_per_launch": w * 1024 / max(1, nw),
        "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units, separate --pmc passes"}
 out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
@@ -35,7 +35,7 @@ def per_kernel(path, counter, scale):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter: continue
         n = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"]).strip()
-        if not any(k in n for k in ("igemm", "swin_mlp", "win_attn", "ae_flash", "gn_", "splitk_reduce", "head_conv")): continue
+        if not any(k in n for k in ("igemm", "wino_kernel", "swin_mlp", "win_attn", "ae_flash", "gn_", "splitk_reduce", "head_conv")): continue
         a = acc.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"]) * 1024 * scale
     return acc
 pf, pw = per_kernel(sys.argv[1], "FETCH_SIZE", 2.0), per_kernel(sys.argv[2], "WRITE_SIZE", 1.0)
