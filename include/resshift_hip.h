@@ -106,6 +106,11 @@ int rs_bind_weight_blob(rs_engine* e, void* dev, size_t bytes);
 /* pack everything loaded so far into the bound blob (GEMM-ready [Cout][kh][kw][Cin] fp16/fp32,
  * expanded relative-position bias tables, codebook, ...); only the broadcasting rank needs to call it */
 int rs_pack_weights(rs_engine* e);
+/* broadcast the bound blob from rank `root` over the HOST's RCCL communicator (`rccl_comm`: an ncclComm_t; one ncclBroadcast of
+ * rs_weight_bytes() bytes, in place, on `stream`): what replaces the reference's per-rank checkpoint load (sampler.py:66-77, utils/util_net.py
+ * reload_model) for a host without torch.distributed.  RCCL is dlopen'ed at call time - no link dependency.  Every rank calls rs_weights_ready()
+ * afterwards. */
+int rs_bcast_weights(rs_engine* e, void* rccl_comm, int root, void* stream);
 /* tell the engine the blob content is valid (after pack or after a broadcast) */
 int rs_weights_ready(rs_engine* e);
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rs_weight_bytes": (_SZ, [_P]),
     "rs_bind_weight_blob": (_I, [_P, _P, _SZ]),
     "rs_pack_weights": (_I, [_P]),
+    "rs_bcast_weights": (_I, [_P, _P, _I, _P]),
     "rs_weights_ready": (_I, [_P]),
     "rs_unet_forward": (_I, [_P, _P, C.POINTER(C.c_int), _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rs_vq_encode": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -20,6 +20,7 @@
 //     config, so a multi-GPU host can broadcast it with a single RCCL call.
 #include "common.h"
 #include "../../include/resshift_hip.h"
+#include <dlfcn.h>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -1917,6 +1918,26 @@ int rs_bind_weight_blob(rs_engine* e, void* dev, size_t bytes) {
     e->bound = true; e->ready = false;
     for (auto& kv : e->film_cache) (void)hipFree(kv.second);
     e->film_cache.clear();
+    return 0;
+}
+
+// Broadcast the bound weight blob from rank `root` over an RCCL communicator the HOST owns (sampler.py:66-77: the reference's
+// ranks each load the checkpoint - here rank 0 packs once and the blob travels over xGMI).  `rccl_comm` is an ncclComm_t; RCCL is looked up at
+// call time (dlopen of librccl.so - the library has no link-time dependency on it: a single-GPU host never needs it).  One ncclBroadcast of
+// rs_weight_bytes() bytes on `stream`, in place; the caller then calls rs_weights_ready() on every rank.  (The Python host mirror broadcasts the
+// same buffer through torch.distributed, backend nccl = RCCL: resshift_amd/sharding.py.)
+int rs_bcast_weights(rs_engine* e, void* rccl_comm, int root, void* stream) {
+    if (!e || !e->bound || !rccl_comm) return fail("rs_bcast_weights: bind a weight blob first and pass an RCCL communicator");
+    typedef int (*bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static bcast_t fn = []() -> bcast_t {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        return h ? (bcast_t)dlsym(h, "ncclBroadcast") : nullptr;
+    }();
+    if (!fn) return fail("rs_bcast_weights: librccl.so (ncclBroadcast) not found");
+    const int rc = fn(e->blob.base, e->blob.base, e->blob_bytes, /* ncclUint8 */ 1, root, rccl_comm, (hipStream_t)stream);
+    if (rc != 0) return fail("rs_bcast_weights: ncclBroadcast failed (ncclResult_t " + std::to_string(rc) + ")");
+    e->ready = false;   // (the receiving ranks' flags are read back by rs_weights_ready)
     return 0;
 }
 

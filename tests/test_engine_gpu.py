@@ -1040,6 +1040,48 @@ def test_bench_launches_its_own_ranks(gpu):
         assert r2.returncode != 0 and "refused" in (r2.stderr + r2.stdout)
 
 
+def test_rs_bcast_weights_over_a_one_rank_rccl_communicator(gpu):
+    """SURVEY 8(b)'s `rs_bcast_weights(engine, rccl_comm, root)`: the C-ABI broadcast of the weight blob for a host without torch.distributed
+    (sampler.py:66-77: what the reference's ranks load from the checkpoint each).  One-GPU boxes cannot show a transfer, but they can show the
+    call path: a ONE-rank RCCL communicator made with RCCL's own C API (ctypes), one ncclBroadcast of the whole blob in place, the engine ready
+    again, and the network's output unchanged bit for bit."""
+    import ctypes as C
+
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so is not on the loader path")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    up, ap, dp, with_mask = H.CASES["tiny"]
+    usd, asd = H.weights(up, ap)
+    um, _ = _shells(up, ap, usd, asd, gpu)
+    y, noises, mask = H.case_inputs(up, ap, dp, with_mask)
+    x, t = noises[1] * 1.3, torch.tensor([2, 2])
+    out0 = um(x.to(gpu), t.to(gpu), prec="split", lq=y.to(gpu)).clone()
+    torch.cuda.synchronize()
+    eng = um.engine()
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0 and comm.value
+    try:
+        rc = eng.lib.rs_bcast_weights(eng._h, comm, 0, eng._stream())
+        assert rc == 0, eng.lib.rs_last_error()
+        torch.cuda.synchronize()
+        assert eng.lib.rs_weights_ready(eng._h) == 0, eng.lib.rs_last_error()
+        out1 = um(x.to(gpu), t.to(gpu), prec="split", lq=y.to(gpu))
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out1)
+        assert eng.lib.rs_bcast_weights(eng._h, None, 0, eng._stream()) != 0   # no communicator: refused, not crashed
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
 def test_bench_two_gpus_over_rccl(gpu):
     """First contact with RCCL (sampler.py:66-77,233-234,273-277,290-291): on a box with >= 2 GPUs `bench.py --gpus 2` must come
     up under backend nccl (= RCCL on ROCm) with one device per rank, broadcast the weight blob ONCE, and give both ranks the same throughput.
