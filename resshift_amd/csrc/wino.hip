@@ -267,10 +267,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
     issue_halo(0, 0);
     issue_halo(1, 1);
     f16x8 wh[W_DEPTH], wl[W_DEPTH];   // fragments of the steps ahead: slot = step % W_DEPTH
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < W_DEPTH; ++s) load_w(0, 0, 0, s, wh[s], wl[s]);
-    wait_vm<0>();
-    __syncthreads();           // the coefficients; chunk 0's LDS-DMA data behind a wait AND a barrier
+    __builtin_amdgcn_sched_barrier(0);
+    // chunk 0 (and the coefficients in front of it) have landed: everything issued behind them - chunk 1's four pieces, the fragment loads - flies on
+    wait_vm<2 * W_UPW + 2 * W_DEPTH>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the coefficients; chunk 0's LDS-DMA data behind a wait AND a barrier
+    asm volatile("" ::: "memory");
     convert_chunk(0, 0);
     WSTAMP(0);
 
