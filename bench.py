@@ -477,7 +477,7 @@ def main():
         ti = steps // 2
         xs = noise[1].contiguous()
         nz = noise[2].contiguous()
-        tt = torch.full((B,), ti, device=dev, dtype=torch.long)
+        tt = torch.full((B,), ti, dtype=torch.long)   # (a HOST tensor: p_sample reads int(t[0]) - on a device tensor that is a sync inside the timed loop)
         mk = {"lq": y}
         if mask is not None:
             mk["mask"] = mask

@@ -531,8 +531,12 @@ struct rs_engine {
                     f16* o = (f16*)dst;  // [Cout][K]
                     for (int co = 0; co < Cout; ++co)
                         for (int ci = 0; ci < Cin; ++ci)
-                            for (int t = 0; t < KH * KW; ++t)
-                                o[(size_t)co * K + (size_t)t * CinP + ci] = (f16)w[((size_t)co * Cin + ci) * KH * KW + t];
+                            for (int t = 0; t < KH * KW; ++t) {
+                                const float wv = w[((size_t)co * Cin + ci) * KH * KW + t];
+                                // (a derived weight - the sub-pixel form's summed taps - can reach 4 |w|: outside the fp16 range it would become inf silently)
+                                if (!(std::fabs(wv) <= 65504.0f) && build_err.empty()) build_err = "fp16 storage needs weights inside the fp16 range: " + wkey;
+                                o[(size_t)co * K + (size_t)t * CinP + ci] = (f16)wv;
+                            }
                 });
             if (cfg.enable_split)
                 c.ws = blob.add(np * 4, [&](char* dst) {

@@ -219,7 +219,7 @@ class ResShiftDiffusion:
             noise = noise[0,].repeat(z_y.shape[0], 1, 1, 1)
         z_sample = self.prior_sample(z_y, noise, model.engine() if isinstance(model, UNetModelSwin) else None)
         for k, i in enumerate(list(range(self.num_timesteps))[::-1]):
-            t = torch.tensor([i] * y.shape[0], device=y.device)
+            t = torch.tensor([i] * y.shape[0])   # (kept on the host: the shells read the step index from it - a device tensor would cost a sync per step)
             out = self.p_sample(model, z_sample, z_y, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
                                 model_kwargs=model_kwargs, noise_repeat=noise_repeat,
                                 noise=None if step_noises is None else step_noises[k])
