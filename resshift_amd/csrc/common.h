@@ -308,6 +308,8 @@ struct WinAttnParams {
     void* out;            // [B,H,W,ldo]: feature head*32 + d
     const float* bias_t;  // [heads][64 (key j)][64 (query i)] relative position bias, transposed (VALU kernel)
     const float* bias_n;  // [heads][64 (query i)][64 (key j)] (MFMA kernel); may be null -> VALU kernel is used
+    const float* bias_c;  // [heads][256]: the 225 distinct values per head (index (dy + 7) * 15 + dx + 7, swin_transformer.py:93-102) x log2 e, zero
+                          // padded - the split fused kernel copies it to LDS with one LDS-DMA instruction per wave (win_attn_split.hip)
     int B, H, W, heads, shift, ldq, ldo;
     float scale;
     // fused qkv projection (win_attn_qkv_kernel): normalised tokens instead of a qkv tensor

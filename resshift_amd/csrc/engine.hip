@@ -173,7 +173,7 @@ struct ConvW {
 };
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResBlockW { GNW n1, n2; ConvW c1, c2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int film_off = -1; ConvW emb; };
-struct SwinBlockW { GNW n1, n2; ConvW qkv, proj, fc1, fc2; float* bias_t = nullptr; float* bias_n = nullptr; int shift = 0; };
+struct SwinBlockW { GNW n1, n2; ConvW qkv, proj, fc1, fc2; float* bias_t = nullptr; float* bias_n = nullptr; float* bias_c = nullptr; int shift = 0; };
 struct BasicLayerW { ConvW embed, unembed; std::vector<SwinBlockW> blocks; int C = 0, E = 0;
                      ConvW unfold; bool has_unfold = false; };   // unfold: [Wu W2 | Wu] of the last block's fc2 and patch_unembed (basiclayer())
 struct UBlock {
@@ -761,6 +761,15 @@ struct rs_engine {
                             o[((size_t)h * 64 + i) * 64 + j] = t->data[(size_t)idx * heads + h];
                         }
             });
+            // compact form for the split fused kernel (WinAttnParams::bias_c): the table itself, head-major, in units of log2
+            s.bias_c = (float*)blob.add((size_t)heads * 256 * 4, [&, tkey, heads](char* dst) {
+                const HostTensor* t = find(tkey);
+                float* o = (float*)dst;
+                std::fill(o, o + (size_t)heads * 256, 0.0f);
+                if (!t || (int)t->data.size() != 225 * heads) return;
+                for (int h = 0; h < heads; ++h)
+                    for (int k = 0; k < 225; ++k) o[h * 256 + k] = t->data[(size_t)k * heads + h] * 1.44269504088896f;
+            });
             s.proj = add_conv(q + ".attn.proj", E, E, 1, 1);
             add_frag_copies(s.proj, q + ".attn.proj");
             s.n2 = add_gn(q + ".norm2", E);
@@ -1310,7 +1319,7 @@ struct rs_engine {
             if (fuse_qkv) {
                 if (!ex.dry) {
                     WinAttnParams p{};
-                    p.bias_n = s.bias_n; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
+                    p.bias_n = s.bias_n; p.bias_c = s.bias_c; p.B = X.B; p.H = X.H; p.W = X.W; p.heads = heads; p.shift = s.shift;
                     p.scale = 1.0f / std::sqrt((float)(E / heads));
                     if (fold1) { p.x = e.p; p.ldx = e.ld; p.xcoef = coef1; } else { p.x = n.p; p.ldx = n.ld; }
                     p.wqkv = s.qkv.w_frag_for(X.dt); p.bqkv = s.qkv.bias;
@@ -2494,8 +2503,12 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
                 bn[((size_t)h * 64 + i) * 64 + j] = table_host[(size_t)idx * heads + h];
             }
     float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
+    std::vector<float> bc((size_t)heads * 256, 0.0f);   // WinAttnParams::bias_c
+    for (int h = 0; h < heads; ++h)
+        for (int k = 0; k < 225; ++k) bc[(size_t)h * 256 + k] = table_host[(size_t)k * heads + h] * 1.44269504088896f;
+    float* dc = (float*)dev_copy(bc.data(), bc.size() * 4);
     WinAttnParams p{};
-    p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
+    p.bias_n = dn; p.bias_c = dc; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
     // fragment-major (hi, lo) weights (ConvW::ws_frag) from the caller's rows [K hi | K lo]
     const int E = heads * 32;
     void* wq_f = frag_major_from_device_rows(wqkv_dev, 3 * E, E, 2 * E, E);
@@ -2505,7 +2518,7 @@ int rs_op_window_attention_qkv_split(const void* x, const void* wqkv_dev, const 
     const int rc = (wq_f && (wp_f || !wproj_dev)) ? rs_win_attn_qkv_split_launch(&p, st) : -1;
     if (rc) fail("fused split qkv + window attention launch rejected the shape (split storage, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
-    (void)hipFree(dn); (void)hipFree(wq_f); (void)hipFree(wp_f);
+    (void)hipFree(dn); (void)hipFree(dc); (void)hipFree(wq_f); (void)hipFree(wp_f);
     return rc;
 }
 

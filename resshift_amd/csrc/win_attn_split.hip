@@ -38,6 +38,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     constexpr int XS_STAGE = NT * 128;          // 64 token rows x 128 B per 64-wide K stage
     constexpr int XS_PLANE = 3 * XS_STAGE;      // hi (or lo) plane of the token tile
     constexpr int VT_HEAD = 2 * HD * VP;        // halfs: [HD][VP] hi, then [HD][VP] lo of one head
+    constexpr int BT_BYTES = 6 * 1024 + 256 + 2048;   // bias table [6 heads][256 floats] + the tail flag's slot + the image's GroupNorm coefficients
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -54,15 +55,25 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     float* const btab = (float*)(smem + 2 * XS_PLANE + 6 * VT_HEAD * 2);
     // residual / output tile (fused projection only; hi plane, lo plane in the token tile format): the shortcut's rows arrive by LDS-DMA,
     // the projection adds its result in place and the finished tile leaves as whole 128-byte lines
-    char* const rt = smem + 2 * XS_PLANE + 6 * VT_HEAD * 2 + 5632;
+    char* const rt = smem + 2 * XS_PLANE + 6 * VT_HEAD * 2 + BT_BYTES;
     // (GroupNorm tail: one LDS word in the slack behind the bias table says whether a wave of this workgroup drew the image's last ticket)
-    unsigned* const tail_flag = (unsigned*)(btab + 1404);
+    unsigned* const tail_flag = (unsigned*)(btab + 6 * 256);
     const bool tail_on = p.tail.coef != nullptr && p.ystats != nullptr;
     if (tid == 0) *tail_flag = 0u;
-    for (int e = tid; e < 6 * 225; e += 384) {
-        const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
-        const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
-        btab[e] = p.bias_n[(hh * NT + i) * NT + j] * 1.44269504088896f;   // in units of log2: the softmax below works in base 2
+    // The table arrives compact and in units of log2 (WinAttnParams::bias_c: the softmax below works in base 2): wave h copies head h's 1 KB with ONE
+    // LDS-DMA instruction, requested in front of the token tile - it lands behind the same wait + barrier.  (Until round 6 every thread gathered
+    // its 3 - 4 values from the dense [h][i][j] table in a loop of dependent loads BEFORE the token requests went out: four exposed round trips
+    // at the head of every window's 30 us.)
+    {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias_c, 0, 6 * 1024, 0x00020000);
+        lds_dma16_ws(rb, (char*)btab + h * 1024, (unsigned)(h * 1024 + lane * 16));
+    }
+    // norm1's coefficients of this image ([2][E] floats = 1536 B) the same way: the fold below reads them from LDS instead of waiting for four
+    // dependent L2 round trips behind the barrier (waves 0 and 1, 1 KB each; the descriptor's bound zero-fills the last 512 B)
+    float* const cf = (float*)((char*)btab + 6 * 1024 + 256);
+    if (p.xcoef && h < 2) {
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.xcoef + (long long)b * 2 * E), 0, 2 * E * 4, 0x00020000);
+        lds_dma16_ws(rc, (char*)cf + h * 1024, (unsigned)(h * 1024 + lane * 16));
     }
     const int shift = p.shift, H = p.H, W = p.W;
     auto pixel = [&](int t) -> long long {
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             lds_dma16_ws(rx, smem + plane * XS_PLANE + st * XS_STAGE + (grp * 8) * 128, off);
         }
     }
-    // the hand-counted vmcnt(24) below assumes the 8 token DMAs are OLDER than the 24 q-weight loads: pin that order (ae_attn.hip does the same)
+    // the hand-counted vmcnt(24) below assumes the bias table's and the 8 token DMAs are OLDER than the 24 q-weight loads: pin that order (ae_attn.hip does the same)
     __builtin_amdgcn_sched_barrier(0);
     const int swz[2] = {(lg ^ (lr & 7)) << 4, ((4 + lg) ^ (lr & 7)) << 4};
     // one projection pass over the token tile: 32 output features starting at weight row n0 (rows [K hi | K lo], K = E) ->
@@ -102,10 +113,15 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
             }
         }
     };
-    auto project = [&](const f16x8 (&wh)[2][KS], const f16x8 (&wl)[2][KS], const float* bias, int n0, f32x4 (&acc)[2][4]) {
+    // (the pass's bias values are requested by the caller IN FRONT of the pass's weight burst: younger than it, the first MFMA waited for the whole burst)
+    auto load_b = [&](const float* bias, int n0, f32x4 (&bv)[2]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bv[f] = *(const f32x4*)(bias + n0 + 16 * f + 4 * lg);
+    };
+    auto project = [&](const f16x8 (&wh)[2][KS], const f16x8 (&wl)[2][KS], const f32x4 (&bias)[2], f32x4 (&acc)[2][4]) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const f32x4 bv = *(const f32x4*)(bias + n0 + 16 * f + 4 * lg) * RS_LO_SCALE;
+            const f32x4 bv = bias[f] * RS_LO_SCALE;
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) acc[f][fi] = bv;
         }
@@ -134,6 +150,41 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) acc[f][fi] = acc[f][fi] * RS_LO_INV;
     };
+    // The same pass with the operands swapped (the fragment registers of the two operands have the same shape): acc[f][fi] holds TOKENS
+    // 16 fi + 4 lg + r of feature 16 f + lr - four consecutive tokens of one feature per lane, i.e. eight-byte pieces of a V^T row (the
+    // feature-major form needed 64 two-byte LDS stores per lane for V^T, this one 16 eight-byte stores).
+    auto project_t = [&](const f16x8 (&wh)[2][KS], const f16x8 (&wl)[2][KS], const float (&bias)[2], f32x4 (&acc)[2][4]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float bv = bias[f] * RS_LO_SCALE;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[f][fi] = f32x4{bv, bv, bv, bv};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 xh[4], xl[4];
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const char* xr = smem + (ks >> 1) * XS_STAGE + (16 * fi + lr) * 128 + swz[ks & 1];
+                xh[fi] = *(const f16x8*)xr;
+                xl[fi] = *(const f16x8*)(xr + XS_PLANE);
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const f16x8 ws = wh[f][ks] * (f16)RS_LO_SCALE;
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[fi], ws, acc[f][fi], 0, 0, 0);
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[fi], wh[f][ks], acc[f][fi], 0, 0, 0);
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) acc[f][fi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[fi], wl[f][ks], acc[f][fi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) acc[f][fi] = acc[f][fi] * RS_LO_INV;
+    };
     // accumulator pair of a token fragment -> the 8 head-dim values of that token as (hi, lo) MFMA operands
     auto pack = [&](const f32x4 (&acc)[2][4], f16x8 (&oh)[4], f16x8 (&ol)[4]) {
 #pragma unroll
@@ -147,6 +198,8 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     };
     const f16* wq = (const f16*)p.wqkv;
     f16x8 wfh[2][KS], wfl[2][KS];
+    f32x4 bq[2];
+    load_b(p.bqkv, h * HD, bq);
     load_w(wq, h * HD, wfh, wfl);     // q_h weights: requested together with the token tile ...
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // ... but only the tile (8 LDS-DMA instructions, older than the 24 weight loads) is waited for here
     __syncthreads();   // the window's tokens are in LDS
@@ -154,7 +207,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     if (p.xcoef) {
         // GroupNorm (norm1) folded in: x * scale[b][c] + shift[b][c] on the joined value, re-split.  64 rows x 24 chunks of 8
         // channels, 4 chunks per thread; LDS position ps of row t holds chunk ps ^ (t & 7).
-        const float* sc = p.xcoef + (long long)b * 2 * E;
+        const float* sc = cf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int item = tid + 384 * q;              // 0 .. 1535
@@ -179,31 +232,36 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     f16x8 kh[4], kl[4], qh[4], ql[4];
     {
         f32x4 acc[2][4];
-        project(wfh, wfl, p.bqkv, h * HD, acc);            // q_h: lane (lr, lg) holds d = {4 lg + r, 16 + 4 lg + r} of token 16 fi + lr
+        project(wfh, wfl, bq, acc);                        // q_h: lane (lr, lg) holds d = {4 lg + r, 16 + 4 lg + r} of token 16 fi + lr
+        load_b(p.bqkv, E + h * HD, bq);
         load_w(wq, E + h * HD, wfh, wfl);
         pack(acc, qh, ql);
         __builtin_amdgcn_sched_barrier(0);
         RS_ATTN_STAMP(3);
-        project(wfh, wfl, p.bqkv, E + h * HD, acc);        // k_h: the same d set per lane -> a consistent contraction order for S^T
+        project(wfh, wfl, bq, acc);                        // k_h: the same d set per lane -> a consistent contraction order for S^T
+        float bvv[2] = {p.bqkv[2 * E + h * HD + lr], p.bqkv[2 * E + h * HD + 16 + lr]};
         load_w(wq, 2 * E + h * HD, wfh, wfl);
         pack(acc, kh, kl);
         __builtin_amdgcn_sched_barrier(0);
         RS_ATTN_STAMP(4);
-        project(wfh, wfl, p.bqkv, 2 * E + h * HD, acc);    // v_h -> V^T[d][token] (hi, lo) in LDS
+        project_t(wfh, wfl, bvv, acc);                     // v_h, tokens along the accumulator rows -> V^T[d][token] (hi, lo) in LDS
 #ifdef RS_ATTN_SPLIT_EARLYW   // (projection weights in flight during the whole attention: 96 registers the softmax then spills; measured equal)
         if (p.wproj) load_w((const f16*)p.wproj, h * HD, wfh, wfl);
 #endif
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
+            for (int ft = 0; ft < 4; ++ft) {
+                f16x4 hv, lv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     f16 a, c;
                     rs_split(acc[f][ft][r], a, c);
-                    vth[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = a;
-                    vtl[(16 * f + 4 * lg + r) * VP + 16 * ft + lr] = c;
+                    hv[r] = a; lv[r] = c;
                 }
+                *(f16x4*)(vth + (16 * f + lr) * VP + 16 * ft + 4 * lg) = hv;
+                *(f16x4*)(vtl + (16 * f + lr) * VP + 16 * ft + 4 * lg) = lv;
+            }
     }
     RS_ATTN_STAMP(5);
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tile (it is overwritten below)
@@ -238,7 +296,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     // win_attn_kernel): every other window takes the mask-free path (a wave-uniform branch).
     const float c2 = p.scale * 1.44269504088896f;
     // bias of (i = 16 fi + lr, j = 16 fj + 4 lg + r) = tb[30 (fi - fj) - r]
-    const float* tb = btab + h * 225 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
+    const float* tb = btab + h * 256 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
     auto softmax = [&](auto MK) {
         constexpr bool MASK = decltype(MK)::value;
         int rid_i = 0, rid_j[4] = {0, 0, 0, 0};
@@ -345,6 +403,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     if (!p.wproj) return;
     RS_ATTN_STAMP(8);   // P V done, results in LDS
     // ---- fused output projection: wave h produces output features 32 h .. 32 h + 31 for all tokens, weights straight from L2
+    load_b(p.bproj, h * HD, bq);
 #ifndef RS_ATTN_SPLIT_EARLYW
     load_w((const f16*)p.wproj, h * HD, wfh, wfl);
 #endif
@@ -352,7 +411,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_split_kernel(WinAttnParams p
     __syncthreads();   // all heads' attention results are in LDS
     RS_ATTN_STAMP(9);
     f32x4 acc2[2][4];
-    project(wfh, wfl, p.bproj, h * HD, acc2);
+    project(wfh, wfl, bq, acc2);
     float s1[2][4], s2[2][4];   // per-channel sums of the stored values (the pair reproduces v to 2^-23) over this lane's four tokens
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -442,7 +501,7 @@ extern "C" int rs_attn_split_phase_cycles(int nwg, int nst, double* out) {
 // split-storage NHWC tensors, wqkv / wproj split weight rows [K hi | K lo]
 extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t st) {
     const WinAttnParams& p = *pp;
-    if ((p.H % 8) || (p.W % 8) || p.heads != 6 || (p.ldx % 8) || (p.ldo % 8) || !p.bias_n || !p.x || !p.wqkv || !p.bqkv) return -2;
+    if ((p.H % 8) || (p.W % 8) || p.heads != 6 || (p.ldx % 8) || (p.ldo % 8) || !p.bias_c || !p.x || !p.wqkv || !p.bqkv) return -2;
     if (p.shift != 0 && p.shift != 4) return -2;
     if (p.wproj && (!p.bproj || (p.res && (p.ldres % 4)))) return -2;
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 4;
@@ -451,7 +510,7 @@ extern "C" int rs_win_attn_qkv_split_launch(const WinAttnParams* pp, hipStream_t
     const size_t rb = p.res ? (size_t)p.B * p.H * p.W * p.ldres * 4 : 0;
     if (rb >= 0xF0000000ull || (p.wproj && p.res && (p.ldres % 8))) return -2;
     // token tile (hi, lo) + V^T (hi, lo) + the bias table (+ with the fused projection the residual / output tile)
-    const size_t lds_max = (size_t)2 * 3 * 64 * 128 + (size_t)6 * 2 * 32 * (64 + 8) * sizeof(f16) + 5632 + (size_t)2 * 3 * 64 * 128;
+    const size_t lds_max = (size_t)2 * 3 * 64 * 128 + (size_t)6 * 2 * 32 * (64 + 8) * sizeof(f16) + (6 * 1024 + 256 + 2048) + (size_t)2 * 3 * 64 * 128;
     const size_t lds = lds_max - (p.wproj ? 0 : (size_t)2 * 3 * 64 * 128);
     static RsAttrFlags attr_flags;
     if (attr_flags.need()) { (void)hipFuncSetAttribute((const void*)win_attn_qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); }
