@@ -2476,8 +2476,12 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
                 bn[((size_t)h * 64 + i) * 64 + j] = table_host[(size_t)idx * heads + h];
             }
     float* dn = (float*)dev_copy(bn.data(), bn.size() * 4);
+    std::vector<float> bc((size_t)heads * 256, 0.0f);   // WinAttnParams::bias_c
+    for (int h = 0; h < heads; ++h)
+        for (int k = 0; k < 225; ++k) bc[(size_t)h * 256 + k] = table_host[(size_t)k * heads + h] * 1.44269504088896f;
+    float* dc = (float*)dev_copy(bc.data(), bc.size() * 4);
     WinAttnParams p{};
-    p.bias_n = dn; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
+    p.bias_n = dn; p.bias_c = dc; p.out = out; p.B = B; p.H = H; p.W = W; p.heads = heads; p.shift = shift; p.ldo = heads * 32; p.scale = 1.0f / std::sqrt(32.0f);
     // the kernel reads its weights in fragment-major order (ConvW::wh_frag): repack the caller's row-major operands
     const int E = heads * 32;
     void* wq_f = frag_major_from_device_rows(wqkv_dev, 3 * E, E, E, -1);
@@ -2487,7 +2491,7 @@ int rs_op_window_attention_qkv(const void* x, const void* wqkv_dev, const float*
     const int rc = (wq_f && (wp_f || !wproj_dev)) ? rs_win_attn_qkv_launch(&p, st) : -1;
     if (rc) fail("fused qkv + window attention launch rejected the shape (fp16, 6 heads of 32 only)");
     (void)hipStreamSynchronize(st);
-    (void)hipFree(dn); (void)hipFree(wq_f); (void)hipFree(wp_f);
+    (void)hipFree(dn); (void)hipFree(dc); (void)hipFree(wq_f); (void)hipFree(wp_f);
     return rc;
 }
 

@@ -797,15 +797,16 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     // The relative position bias of (query i, key j) depends on (y_i - y_j, x_i - x_j) only: 225 values per head
     // (swin_transformer.py:93-102).  They are copied once per workgroup from the dense [h][i][j] table into LDS (5.4 KB) and the softmax
     // reads them from there with constant offsets - instead of 16 KB per head and window through L2 (a third of this kernel's traffic).
-    constexpr int BT_BYTES = 5632;                           // 6 x 225 floats, padded to a multiple of 256 B
+    constexpr int BT_BYTES = 6144;                           // [6 heads][256 floats]: 225 values per head, zero padded (WinAttnParams::bias_c)
     float* const btab = (float*)(smem + NW * (XS_WIN + 6 * HD * VP * 2));
     // residual / output tile of window w (fused projection only): the shortcut rows arrive here by LDS-DMA (token tile format), the
     // projection adds its result in place and the finished tile leaves as whole 128-byte lines
     auto rt_of = [&](int w) { return smem + NW * (XS_WIN + 6 * HD * VP * 2) + BT_BYTES + w * XS_WIN; };
-    for (int e = tid; e < 6 * 225; e += 384) {
-        const int hh = e / 225, k = e - hh * 225, dy = k / 15 - 7, dx = k - (k / 15) * 15 - 7;
-        const int i = ((dy > 0 ? dy : 0) << 3) + (dx > 0 ? dx : 0), j = ((dy < 0 ? -dy : 0) << 3) + (dx < 0 ? -dx : 0);
-        btab[e] = p.bias_n[(hh * NT + i) * NT + j] * 1.44269504088896f;   // in units of log2: the softmax below works in base 2
+    // (round 6: the table arrives compact and in units of log2 - the softmax below works in base 2 - by ONE LDS-DMA instruction per wave, in front
+    // of the token requests; the gather loop of dependent loads it replaces stood in front of them, see win_attn_split.hip)
+    {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias_c, 0, 6 * 1024, 0x00020000);
+        lds_dma16_vs(rb, (char*)btab + h * 1024, (unsigned)(h * 1024 + lane * 16), 0u);
     }
     auto win_y = [&](int w) { return (int)(blockIdx.x * NW + w) / nwx; };
     auto pixel = [&](int w, int t) -> long long {
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(384) void win_attn_qkv_kernel(WinAttnParams p, unsi
     __syncthreads();  // V^T of every head is in LDS; every wave is done with the token tiles (they are overwritten below)
     RS_ATTN_STAMP(6);
     // bias of (i = 16 fi + lr, j = 16 fj + 4 lg + r) = tb[30 (fi - fj) - r]
-    const float* tb = btab + h * 225 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
+    const float* tb = btab + h * 256 + ((lr >> 3) - (lg >> 1) + 7) * 15 + (lr & 7) - 4 * (lg & 1) + 7;
     f16* out = (f16*)p.out;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -1122,7 +1123,7 @@ extern "C" int rs_attn_phase_cycles(int nwg, int nst, double* out) {
 extern "C" int rs_win_attn_qkv_supported(int heads, int E) { return heads == 6 && E == 192; }
 extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     const WinAttnParams& p = *pp;
-    if ((p.H % 8) || (p.W % 8) || !rs_win_attn_qkv_supported(p.heads, 32 * p.heads) || (p.ldx % 8) || (p.ldo % 8) || !p.bias_n) return -2;
+    if ((p.H % 8) || (p.W % 8) || !rs_win_attn_qkv_supported(p.heads, 32 * p.heads) || (p.ldx % 8) || (p.ldo % 8) || !p.bias_c) return -2;
     if (p.shift != 0 && p.shift != 4) return -2;
     if (p.wproj && (!p.bproj || (p.res && (p.ldres % 4)))) return -2;
     const size_t xb = (size_t)p.B * p.H * p.W * p.ldx * 2;
@@ -1134,7 +1135,7 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
     const size_t rb = p.res ? (size_t)p.B * p.H * p.W * p.ldres * 2 : 0;
     if (rb >= 0xF0000000ull || (p.wproj && p.res && (p.ldres % 8))) return -2;
     // token tiles + V^T + the bias table (+ with the fused projection one residual / output tile per window)
-    const size_t lds = (size_t)NW * (3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16)) + 5632 + (p.wproj ? (size_t)NW * 3 * 64 * 128 : 0);
+    const size_t lds = (size_t)NW * (3 * 64 * 128 + (size_t)p.heads * 32 * (64 + 8) * sizeof(f16)) + 6144 + (p.wproj ? (size_t)NW * 3 * 64 * 128 : 0);
 #ifdef RS_SPLIT_ABLATE
     {
         static const int abl = []() { const char* v = getenv("RS_ATTN_ABL"); const int a = v ? atoi(v) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &a, sizeof(int)); return a; }();
@@ -1145,8 +1146,8 @@ extern "C" int rs_win_attn_qkv_launch(const WinAttnParams* pp, hipStream_t st) {
         static RsAttrFlags attr_flags;
         if (attr_flags.need()) {
             const int per_win = 3 * 64 * 128 + 6 * 32 * (64 + 8) * 2 + 3 * 64 * 128;
-            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * per_win + 5632);
-            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, per_win + 5632);
+            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * per_win + 6144);
+            (void)hipFuncSetAttribute((const void*)win_attn_qkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, per_win + 6144);
         }
     }
     if (NW == 2) hipLaunchKernelGGL(win_attn_qkv_kernel<2>, dim3(nwin / 2, p.B), dim3(64 * p.heads), lds, st, p, (unsigned)xb, (unsigned)rb);
