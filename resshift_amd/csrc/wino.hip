@@ -64,7 +64,7 @@ constexpr int W_NBUF = 3;                   // halo buffers: chunk c computes, c
 constexpr int W_COEF = W_NBUF * W_HBUF;     // GroupNorm coefficients [2][Cin] fp32
 constexpr int W_MAXCIN = 640;               // coefficient table: 5 120 B
 constexpr int W_LDS = 160 * 1024;
-static_assert(W_COEF + W_MAXCIN * 8 <= W_LDS, "LDS");
+static_assert(W_COEF + W_MAXCIN * 8 <= W_LDS && W_COEF + 8 * 1024 <= W_LDS, "LDS");   // (the table arrives as 8 x 1 KB LDS-DMA pieces)
 constexpr unsigned W_INV = 0xF0000000u;
 // weight fragments are requested W_DEPTH steps (6 MFMAs each) ahead: as many register slots as the accumulators leave room for
 __host__ __device__ constexpr int w_depth_of(int CF) { return CF <= 8 ? 4 : 2; }
@@ -261,8 +261,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(IGemmParams p) {
 
     // ---- prologue: coefficients -> LDS, chunks 0 and 1 on their way, chunk 0 converted, the first steps' weights
     if (xcoef) {
-        const float* src = xcoef + (long long)b * 2 * Cin;
-        for (int i = tid; i < 2 * Cin; i += 512) ((float*)(smem + W_COEF))[i] = src[i];
+        // one LDS-DMA instruction per wave (1 KB each; the descriptor's bound zero-fills what lies behind the image's 2 Cin floats), in front of the
+        // halo requests: it lands behind the same wait + barrier as chunk 0.  (The copy loop it replaces - load, wait, ds_write, up to three
+        // dependent round trips - stood in front of the first halo request of every workgroup.)
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(xcoef + (long long)b * 2 * Cin), 0, 2 * Cin * 4, 0x00020000);
+        wdma16s(rc, smem + W_COEF + wave * 1024, (unsigned)(wave * 1024 + lane * 16), 0u);
     }
     issue_halo(0, 0);
     issue_halo(1, 1);
